@@ -1,0 +1,148 @@
+/* libplonk_hip: MI355X (gfx950) backend for the prover hot path of sabrinahirani/PLONK.
+ *
+ * Plain C ABI.  The reference has no FFI of its own: each entry point below names the reference
+ * function (or third-party call made by the reference) whose arithmetic it replaces.  RNG, the
+ * Poseidon opening challenge, the merlin transcript and serialization stay in the caller.
+ *
+ * Conventions
+ *   - Field elements: 4 little-endian uint64_t limbs in Montgomery form (x * 2^256 mod p), i.e. the
+ *     in-memory payload of arkworks' Fp256.  Fr = BN254 scalar field, Fq = base field.
+ *   - G1 points: x || y (8 limbs) plus a separate infinity flag.  Never a Rust struct by pointer.
+ *   - Indices: uint64_t.  Status: int32_t, 0 = PLK_OK.  Nothing aborts or throws across the ABI.
+ *   - "host" pointers are ordinary memory owned by the caller; "dev" pointers are device memory
+ *     obtained from plk_malloc (or any hipMalloc'd memory of the same device).
+ *   - Calls on one plk_ctx must be serialised by the caller (the reference is single threaded).
+ */
+#ifndef PLONK_HIP_H
+#define PLONK_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plk_ctx plk_ctx;
+
+enum {
+    PLK_OK = 0,
+    PLK_ERR_INVALID_ARG = 1,
+    PLK_ERR_HIP = 2,              /* a HIP runtime call failed; see plk_last_error */
+    PLK_ERR_NO_DEVICE = 3,
+    PLK_ERR_SRS_TOO_SHORT = 4,    /* arkworks: Error::TooManyCoefficients (unwrap panics, src/prover.rs:150) */
+    PLK_ERR_NOT_DIVISIBLE = 5,    /* assert!(remainder.is_zero(), "t(X) not divisible by Z_H(X)") src/circuit.rs:487 */
+    PLK_ERR_INVERSE_OF_ZERO = 6,  /* .inverse().unwrap() on zero, src/circuit.rs:377,523 */
+    PLK_ERR_INDEX_OUT_OF_RANGE = 7, /* sigma entry >= 3n (index panic in src/circuit.rs:508-510) */
+    PLK_ERR_ALLOC = 8
+};
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int32_t plk_create(int32_t device, plk_ctx** out);
+int32_t plk_destroy(plk_ctx* ctx);
+const char* plk_last_error(plk_ctx* ctx);
+
+/* ---- device memory ---------------------------------------------------------------------- */
+int32_t plk_malloc(plk_ctx* ctx, uint64_t bytes, void** dev);
+int32_t plk_free(plk_ctx* ctx, void* dev);
+int32_t plk_upload(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
+int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
+int32_t plk_sync(plk_ctx* ctx);
+
+/* ---- structured reference string (KZGProverKey, src/prover.rs:32; built by PCS::trim, src/main.rs:183)
+ * powers_of_g[0..len) and powers_of_gamma_g[0..3) as affine x||y.  The library keeps them resident in
+ * HBM together with its window tables (2^(16 j) * P for each window j).  With n_shards > 1 this context
+ * keeps only powers [shard_first, shard_first + shard_len) and every MSM it runs is the partial sum over
+ * that range; the gamma powers belong to the shard that contains index 0. */
+int32_t plk_srs_load(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t len, const uint64_t* gamma_g_xy_host);
+int32_t plk_srs_load_shard(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t shard_first, uint64_t shard_len,
+                           uint64_t total_len, const uint64_t* gamma_g_xy_host);
+/* Synthetic SRS with a known trapdoor (what PCS::setup draws from its rng, src/main.rs:182):
+ * powers_of_g[i] = tau^i G, powers_of_gamma_g[j] = gscal tau^j G, computed on the device. */
+int32_t plk_srs_generate(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t len);
+int32_t plk_srs_generate_shard(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t shard_first,
+                               uint64_t shard_len, uint64_t total_len);
+/* Reads points back: which = 0 powers_of_g (global index first..first+count), 1 powers_of_gamma_g. */
+int32_t plk_srs_read(plk_ctx* ctx, int32_t which, uint64_t first, uint64_t count, uint64_t* out_xy_host);
+
+/* ---- variable-base MSM (ark-ec VariableBaseMSM::msm_bigint, reached from PCS::commit / PCS::open,
+ * src/prover.rs:150-156,210,253,295-303):  sum_i scalars[i] * powers_of_g[base_offset + i]. */
+int32_t plk_msm(plk_ctx* ctx, const uint64_t* scalars_host, uint64_t k, uint64_t base_offset, uint64_t out_xy[8],
+                int32_t* out_is_inf);
+int32_t plk_msm_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k, uint64_t base_offset, uint64_t out_xy[8],
+                    int32_t* out_is_inf);
+/* Partial result of this context's shard as an unnormalised point X,Y,ZZ,ZZZ (x = X/ZZ, y = Y/ZZZ;
+ * ZZ = 0 is the identity), 16 limbs.  plk_g1_sum_partials adds such partials and normalises. */
+int32_t plk_msm_partial_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k, uint64_t base_offset, uint64_t out_xyzz[16]);
+int32_t plk_g1_sum_partials(const uint64_t* xyzz, uint64_t count, uint64_t out_xy[8], int32_t* out_is_inf);
+
+/* ---- radix-2 NTT (ark-poly Radix2EvaluationDomain::fft / ifft; src/prover.rs:232,233,237,
+ * src/circuit.rs:404,438,454,543, src/poly_utils.rs:9,27,28).  In place, natural order in and out, size 2^log_n.
+ * inverse != 0 multiplies by n^-1.  coset_gen != NULL: forward evaluates on g*w^i, inverse interpolates from it. */
+int32_t plk_ntt(plk_ctx* ctx, uint64_t* data_host, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen);
+int32_t plk_ntt_dev(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen);
+
+/* ---- interpolation helpers (src/poly_utils.rs:7-11 and :14-31).  sigma has sigma_len <= 2^log_n4 entries and is
+ * padded with the identity; outputs are 2^log_n4 coefficients each (the caller strips trailing zeros, as
+ * DensePolynomial::from_coefficients_vec does). */
+int32_t plk_interpolate_selector(plk_ctx* ctx, const uint64_t* values_host, uint64_t len, uint64_t* coeffs_out_host, uint32_t* log_n_out);
+int32_t plk_interpolate_permutation(plk_ctx* ctx, const uint64_t* sigma_host, uint64_t sigma_len, uint32_t log_n4,
+                                    uint64_t* s_id_out_host, uint64_t* s_sigma_out_host);
+int32_t plk_interpolate_permutation_dev(plk_ctx* ctx, const void* sigma_dev, uint64_t sigma_len, uint32_t log_n4,
+                                        void* s_id_out_dev, void* s_sigma_out_dev);
+
+/* ---- Circuit::build_grand_product (src/circuit.rs:491-544) with s_id_vals[j] = j (src/prover.rs:205).
+ * witness_flat: 3n Fr ([A_i,B_i,C_i]); sigma: 3n indices; out: n coefficients of ifft(z[0..n)). */
+int32_t plk_grand_product(plk_ctx* ctx, const uint64_t* witness_flat_host, const uint64_t* sigma_host, uint32_t log_n,
+                          const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_coeffs_out_host);
+int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n,
+                              const uint64_t beta[4], const uint64_t gamma[4], void* z_coeffs_out_dev);
+
+/* ---- Circuit::build_quotient_polynomial (src/circuit.rs:442-489) incl. build_permutation_constraint (:343-405)
+ * and the all-zero public-input polynomial of src/prover.rs:224-227.  Columns are values on H (n each).
+ * Writes the coefficients of t into t_out (n entries, zero filled) and their count (0 for the zero polynomial).
+ * Returns PLK_ERR_NOT_DIVISIBLE when the numerator is not a multiple of X^n - 1. */
+int32_t plk_quotient(plk_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* q_add_vals,
+                     const uint64_t* q_mul_vals, const uint64_t* z_vals, const uint64_t* sigma, uint32_t log_n,
+                     const uint64_t beta[4], const uint64_t gamma[4], uint64_t* t_out_host, uint64_t* t_len);
+int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals,
+                         const void* q_mul_vals, const void* z_vals, const void* sigma, uint32_t log_n,
+                         const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev, uint64_t* t_len);
+
+/* ---- DensePolynomial::evaluate (src/prover.rs:266-274) */
+int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t x[4], uint64_t out[4]);
+int32_t plk_poly_eval_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], uint64_t out[4]);
+
+/* ---- PCS::commit with hiding bound 1 (ark-poly-commit kzg10::commit; src/prover.rs:150-156,210,253):
+ * C = sum coeffs[i] powers_of_g[i] + sum_{j<3} blind[j] powers_of_gamma_g[j].  blind = 12 limbs. */
+int32_t plk_kzg_commit(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t* blind, uint64_t out_xy[8], int32_t* out_is_inf);
+int32_t plk_kzg_commit_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, uint64_t out_xy[8], int32_t* out_is_inf);
+/* ---- PCS::open for one polynomial (marlin_pc::open + kzg10::open; src/prover.rs:295-303): opens challenge*f with
+ * randomness challenge*r at zeta.  W = MSM((challenge f)/(X - zeta)) + MSM_gamma((challenge r)/(X - zeta)),
+ * random_v = (challenge r)(zeta), eval = f(zeta) (the division's remainder divided by challenge). */
+int32_t plk_kzg_open(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                     const uint64_t challenge[4], uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]);
+int32_t plk_kzg_open_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                         const uint64_t challenge[4], uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]);
+
+/* Split forms of the two calls above: *_begin enqueues the device work on one of the context's streams and
+ * returns a ticket; *_end waits for it and returns the result.  Several tickets may be open at once, which is how
+ * the seven round-1 commitments and the nine openings of src/prover.rs overlap their latency-bound tails. */
+int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int32_t* ticket);
+int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out_xy[8], int32_t* out_is_inf);
+int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                           const uint64_t challenge[4], int32_t* ticket);
+int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]);
+/* Like *_end but returns this shard's unnormalised partial (16 limbs) instead of the affine point. */
+int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]);
+
+/* ---- element-wise field helpers used by tests and the microbenchmarks (op: 0 add, 1 sub, 2 mul; field: 0 Fr, 1 Fq) */
+int32_t plk_field_op(plk_ctx* ctx, int32_t field, int32_t op, const uint64_t* a_host, const uint64_t* b_host, uint64_t* out_host, uint64_t n);
+
+/* ---- measurement: accumulated device time (HIP events on the launching stream) and launch count of the named
+ * kernel class since the last reset: "msm_accumulate", "msm_sort", "msm_reduce", "ntt", "pointwise", "division". */
+int32_t plk_profile_enable(plk_ctx* ctx, int32_t on);
+int32_t plk_profile_reset(plk_ctx* ctx);
+int32_t plk_profile_get(plk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,287 @@
+// Context lifecycle, device memory helpers, measurement hooks and the KZG commit / open entry points.
+#include "common.cuh"
+#include "host_math.hpp"
+#include "kernels.h"
+#include <stdio.h>
+
+namespace plk {
+
+int32_t set_err(plk_ctx* ctx, int32_t code, const char* what, hipError_t e, int line) {
+    if (ctx) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s failed: %s (line %d)", what, hipGetErrorString(e), line);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+void prof_begin(plk_ctx* ctx, hipStream_t s, const char* name) {
+    if (!ctx->profiling) return;
+    PendingEvent p;
+    p.name = name;
+    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
+    hipEventRecord(p.e0, s);
+    ctx->pending.push_back(p);
+}
+void prof_end(plk_ctx* ctx, hipStream_t s) {
+    if (!ctx->profiling || ctx->pending.empty()) return;
+    hipEventRecord(ctx->pending.back().e1, s);
+}
+void prof_collect(plk_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            ProfEntry& e = ctx->prof[p.name];
+            e.ms += ms;
+            e.launches += 1;
+        }
+        hipEventDestroy(p.e0);
+        hipEventDestroy(p.e1);
+    }
+    ctx->pending.clear();
+}
+
+int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes) {
+    if (bytes <= ctx->scratch_cap) return PLK_OK;
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) PLK_HIP(hipFree(ctx->scratch));
+    ctx->scratch = nullptr; ctx->scratch_cap = 0;
+    PLK_HIP(hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_cap = bytes;
+    return PLK_OK;
+}
+
+static int32_t grow(plk_ctx* ctx, hipStream_t st, uint32_t** buf, uint64_t* cap, uint64_t words) {
+    if (words <= *cap) return PLK_OK;
+    PLK_HIP(hipStreamSynchronize(st));
+    if (*buf) PLK_HIP(hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    PLK_HIP(hipMalloc(buf, words * 4));
+    *cap = words;
+    return PLK_OK;
+}
+
+// orders the slot's stream after everything already enqueued on the compute stream
+static int32_t slot_after_compute(plk_ctx* ctx, MsmSlot& s) {
+    hipEvent_t ev;
+    PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PLK_HIP(hipEventRecord(ev, ctx->stream));
+    PLK_HIP(hipStreamWaitEvent(s.stream, ev, 0));
+    PLK_HIP(hipEventDestroy(ev));
+    return PLK_OK;
+}
+
+}  // namespace plk
+
+using namespace plk;
+
+extern "C" int32_t plk_create(int32_t device, plk_ctx** out) {
+    if (!out) return PLK_ERR_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PLK_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return PLK_ERR_INVALID_ARG;
+    plk_ctx* ctx = new plk_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&ctx->flag_dev, 64) != hipSuccess || hipHostMalloc(&ctx->flag_host, 64, hipHostMallocDefault) != hipSuccess) {
+        delete ctx;
+        return PLK_ERR_HIP;
+    }
+    *out = ctx;
+    return PLK_OK;
+}
+extern "C" int32_t plk_destroy(plk_ctx* ctx) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    prof_collect(ctx);
+    for (auto& s : ctx->slot) slot_destroy(s);
+    ntt_release(ctx);
+    hipFree(ctx->tables); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PLK_OK;
+}
+extern "C" const char* plk_last_error(plk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int32_t plk_malloc(plk_ctx* ctx, uint64_t bytes, void** dev) {
+    if (!ctx || !dev) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (hipMalloc(dev, bytes ? bytes : 32) != hipSuccess) { ctx->err = "device allocation failed"; return PLK_ERR_ALLOC; }
+    return PLK_OK;
+}
+extern "C" int32_t plk_free(plk_ctx* ctx, void* dev) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipFree(dev));
+    return PLK_OK;
+}
+extern "C" int32_t plk_upload(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dev_dst || !host_src))) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLK_OK;
+}
+extern "C" int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes) {
+    if (!ctx || (bytes && (!host_dst || !dev_src))) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLK_OK;
+}
+extern "C" int32_t plk_sync(plk_ctx* ctx) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipDeviceSynchronize());
+    prof_collect(ctx);
+    return PLK_OK;
+}
+
+extern "C" int32_t plk_profile_enable(plk_ctx* ctx, int32_t on) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    ctx->profiling = on != 0;
+    return PLK_OK;
+}
+extern "C" int32_t plk_profile_reset(plk_ctx* ctx) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    prof_collect(ctx);
+    ctx->prof.clear();
+    return PLK_OK;
+}
+extern "C" int32_t plk_profile_get(plk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches) {
+    if (!ctx || !name || !total_ms || !launches) return PLK_ERR_INVALID_ARG;
+    prof_collect(ctx);
+    auto it = ctx->prof.find(name);
+    *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return PLK_OK;
+}
+
+// ---- KZG commit ------------------------------------------------------------------------------------
+extern "C" int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int32_t* ticket) {
+    if (!ctx || !blind || !ticket || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    int si;
+    PLK_TRY(msm_acquire_slot(ctx, &si));
+    MsmSlot& s = ctx->slot[si];
+    PLK_TRY(slot_after_compute(ctx, s));
+    memcpy(s.blind_host, blind, 96);
+    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 96, hipMemcpyHostToDevice, s.stream));
+    PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)coeffs_dev, len, 0, 3));
+    s.busy = true; s.kind = 1;
+    *ticket = si;
+    return PLK_OK;
+}
+static int32_t ticket_slot(plk_ctx* ctx, int32_t ticket, int kind, MsmSlot** out) {
+    if (!ctx || ticket < 0 || ticket >= MSM_SLOTS || !ctx->slot[ticket].busy || ctx->slot[ticket].kind != kind) {
+        if (ctx) ctx->err = "bad ticket";
+        return PLK_ERR_INVALID_ARG;
+    }
+    *out = &ctx->slot[ticket];
+    return PLK_OK;
+}
+extern "C" int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out_xy[8], int32_t* out_is_inf) {
+    MsmSlot* s;
+    PLK_TRY(ticket_slot(ctx, ticket, 1, &s));
+    if (!out_xy || !out_is_inf) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    host::pt r;
+    const int32_t rc = msm_wait(ctx, *s, &r);
+    s->busy = false;
+    prof_collect(ctx);
+    PLK_TRY(rc);
+    host::pt_to_affine(r, out_xy, out_is_inf);
+    return PLK_OK;
+}
+extern "C" int32_t plk_kzg_commit_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, uint64_t out_xy[8], int32_t* out_is_inf) {
+    int32_t t;
+    PLK_TRY(plk_kzg_commit_begin(ctx, coeffs_dev, len, blind, &t));
+    return plk_kzg_commit_end(ctx, t, out_xy, out_is_inf);
+}
+extern "C" int32_t plk_kzg_commit(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t* blind, uint64_t out_xy[8], int32_t* out_is_inf) {
+    if (!ctx || (len && !coeffs_host)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    if (len) { PLK_HIP(hipMalloc(&d, len * 32)); PLK_HIP(hipMemcpy(d, coeffs_host, len * 32, hipMemcpyHostToDevice)); }
+    const int32_t rc = plk_kzg_commit_dev(ctx, d, len, blind, out_xy, out_is_inf);
+    if (d) hipFree(d);
+    return rc;
+}
+
+// ---- KZG open --------------------------------------------------------------------------------------
+extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                                      const uint64_t challenge[4], int32_t* ticket) {
+    if (!ctx || !blind || !zeta || !challenge || !ticket || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    int si;
+    PLK_TRY(msm_acquire_slot(ctx, &si));
+    MsmSlot& s = ctx->slot[si];
+    PLK_TRY(grow(ctx, s.stream, &s.scal_dev, &s.scal_cap, (len + 1) * 8));
+    PLK_TRY(grow(ctx, s.stream, &s.chain_dev, &s.chain_cap, division_work_words(len)));
+    PLK_TRY(slot_after_compute(ctx, s));
+    // witness polynomial of challenge*f: scalars challenge * h_i, i >= 1; h_0 = f(zeta)
+    PLK_TRY(division_enqueue(ctx, s.stream, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev));
+    PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, s.stream));
+    // hiding part on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2, random_v = r'(zeta)
+    using namespace host;
+    const el z = el_load(zeta), ch = el_load(challenge);
+    const el r0 = mul(FR, ch, el_load(blind)), r1 = mul(FR, ch, el_load(blind + 4)), r2 = mul(FR, ch, el_load(blind + 8));
+    const el hw1 = r2, hw0 = add(FR, r1, mul(FR, z, r2));
+    const el rv = add(FR, r0, mul(FR, z, hw0));
+    memcpy(s.host_rv, rv.v, 32);
+    memcpy(s.blind_host, hw0.v, 32);
+    memcpy(s.blind_host + 8, hw1.v, 32);
+    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 64, hipMemcpyHostToDevice, s.stream));
+    PLK_TRY(msm_enqueue(ctx, s, s.scal_dev, len >= 2 ? len - 1 : 0, 0, 2));
+    s.busy = true; s.kind = 2;
+    *ticket = si;
+    return PLK_OK;
+}
+extern "C" int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]) {
+    MsmSlot* s;
+    PLK_TRY(ticket_slot(ctx, ticket, 2, &s));
+    if (!w_xy || !w_is_inf || !random_v || !eval) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    host::pt r;
+    const int32_t rc = msm_wait(ctx, *s, &r);
+    s->busy = false;
+    prof_collect(ctx);
+    PLK_TRY(rc);
+    host::pt_to_affine(r, w_xy, w_is_inf);
+    memcpy(random_v, s->host_rv, 32);
+    memcpy(eval, s->res_host, 32);
+    return PLK_OK;
+}
+extern "C" int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]) {
+    if (!ctx || ticket < 0 || ticket >= MSM_SLOTS || !ctx->slot[ticket].busy || !out_xyzz) return PLK_ERR_INVALID_ARG;
+    MsmSlot* s = &ctx->slot[ticket];
+    PLK_HIP(hipSetDevice(ctx->device));
+    host::pt r;
+    const int32_t rc = msm_wait(ctx, *s, &r);
+    s->busy = false;
+    prof_collect(ctx);
+    PLK_TRY(rc);
+    host::pt_store(r, out_xyzz);
+    if (s->kind == 2) {
+        if (random_v) memcpy(random_v, s->host_rv, 32);
+        if (eval) memcpy(eval, s->res_host, 32);
+    }
+    return PLK_OK;
+}
+extern "C" int32_t plk_kzg_open_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                                    const uint64_t challenge[4], uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]) {
+    int32_t t;
+    PLK_TRY(plk_kzg_open_begin(ctx, coeffs_dev, len, blind, zeta, challenge, &t));
+    return plk_kzg_open_end(ctx, t, w_xy, w_is_inf, random_v, eval);
+}
+extern "C" int32_t plk_kzg_open(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                                const uint64_t challenge[4], uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]) {
+    if (!ctx || (len && !coeffs_host)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    if (len) { PLK_HIP(hipMalloc(&d, len * 32)); PLK_HIP(hipMemcpy(d, coeffs_host, len * 32, hipMemcpyHostToDevice)); }
+    const int32_t rc = plk_kzg_open_dev(ctx, d, len, blind, zeta, challenge, w_xy, w_is_inf, random_v, eval);
+    if (d) hipFree(d);
+    return rc;
+}

@@ -1,0 +1,160 @@
+// Shared declarations of libplonk_hip: the context object, error plumbing and small device helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/plonk_hip.h"
+#include "g1.cuh"
+
+namespace plk {
+
+// Window layout of the MSM: 16 signed 16-bit digits per scalar, one shared set of 2^15 buckets
+// (digit magnitude 1..32768 -> bucket 0..32767) because every window has its own table of 2^(16 j) * P.
+constexpr int MSM_C = 16;
+constexpr int MSM_WINDOWS = 16;
+constexpr int MSM_BUCKETS = 1 << 15;
+constexpr int MSM_MAX_BLOCKS = 128;     // blocks of the counting / scatter kernels (rows of the count matrix)
+constexpr int MSM_SLOTS = 4;            // MSMs in flight
+constexpr int MSM_MARGINALS = 56;       // 16 + 16 + 16 + 8 partial sums handed to the host
+constexpr int XYZZ_WORDS = 36;          // unnormalised point in device scratch: 4 coordinates x 9 limbs
+
+struct MsmSeg {
+    const uint32_t* scalars;   // count Fr elements, 8 words each, x*2^256 form
+    uint32_t count;
+    uint32_t table_off;        // index of the first base inside a window table
+};
+struct MsmSegs {
+    MsmSeg s[2];
+    uint32_t nseg;
+    uint32_t total;
+};
+
+struct ProfEntry {
+    double ms = 0;
+    uint64_t launches = 0;
+};
+struct PendingEvent {
+    hipEvent_t e0, e1;
+    std::string name;
+};
+
+struct MsmSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    uint32_t* counts = nullptr;        // [MSM_MAX_BLOCKS][MSM_BUCKETS]
+    uint32_t* totals = nullptr;        // [MSM_BUCKETS]
+    uint32_t* bucket_start = nullptr;  // [MSM_BUCKETS + 1]
+    uint32_t* entries = nullptr;       // sorted (table index | sign << 31)
+    uint64_t entries_cap = 0;
+    uint32_t* bucket_sums = nullptr;   // [MSM_BUCKETS][XYZZ_WORDS]
+    uint32_t* marg_dev = nullptr;      // [MSM_MARGINALS][32]
+    uint32_t* marg_host = nullptr;     // pinned
+    uint32_t* blind_dev = nullptr;     // 3 Fr (+ room for opening scalars)
+    uint32_t* blind_host = nullptr;    // pinned staging
+    uint32_t* scal_dev = nullptr;      // opening: quotient scalars
+    uint64_t scal_cap = 0;
+    uint32_t* chain_dev = nullptr;     // opening: per-chunk carries of the division scan
+    uint64_t chain_cap = 0;
+    uint32_t* res_dev = nullptr;       // opening: remainder (f(zeta) * challenge) and friends
+    uint32_t* res_host = nullptr;      // pinned
+    bool busy = false;
+    int kind = 0;                      // 0 msm, 1 commit, 2 open
+    uint64_t host_rv[4], host_chal[4]; // opening: values finished on the host
+};
+
+}  // namespace plk
+
+struct plk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // NTT / pointwise work
+    plk::MsmSlot slot[plk::MSM_SLOTS];
+    int next_slot = 0;
+    // SRS
+    uint64_t srs_total = 0, shard_first = 0, shard_len = 0;
+    bool has_gamma = false;
+    uint64_t table_stride = 0;         // points per window table: shard_len + 3 (gamma powers at the end)
+    uint32_t* tables = nullptr;        // [MSM_WINDOWS][table_stride] affine, 16 words each, x*2^261 form
+    // NTT
+    std::map<int, uint32_t*> twiddles; // log_n -> w^i for i < n/2, x*2^261 form
+    uint32_t* ntt_tmp[2] = {nullptr, nullptr};
+    uint64_t ntt_tmp_cap = 0;
+    // scratch for pointwise / scan kernels
+    uint32_t* scratch = nullptr;
+    uint64_t scratch_cap = 0;
+    uint32_t* flag_dev = nullptr;
+    uint32_t* flag_host = nullptr;
+    // profiling
+    bool profiling = false;
+    std::map<std::string, plk::ProfEntry> prof;
+    std::vector<plk::PendingEvent> pending;
+    std::string err;
+};
+
+namespace plk {
+
+int32_t set_err(plk_ctx* ctx, int32_t code, const char* what, hipError_t e, int line);
+#define PLK_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) return plk::set_err(ctx, PLK_ERR_HIP, #call, e_, __LINE__); \
+    } while (0)
+#define PLK_TRY(call)                      \
+    do {                                   \
+        int32_t rc_ = (call);              \
+        if (rc_ != PLK_OK) return rc_;     \
+    } while (0)
+
+// profiling brackets (no-ops unless enabled)
+void prof_begin(plk_ctx* ctx, hipStream_t s, const char* name);
+void prof_end(plk_ctx* ctx, hipStream_t s);
+void prof_collect(plk_ctx* ctx);
+
+int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes);
+
+// ---- device helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ void load8(const uint32_t* p, uint32_t* w) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store8(uint32_t* p, const uint32_t* w) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// 32-byte element in memory -> limbs (value unchanged)
+__device__ __forceinline__ fe ld_fe(const uint32_t* p) {
+    uint32_t w[8];
+    load8(p, w);
+    return unpack(w);
+}
+// normalized, bound 2 -> canonical 32 bytes
+template <class F>
+__device__ __forceinline__ void st_fe(uint32_t* p, const fe& a) {
+    uint32_t w[8];
+    pack(reduce<F>(a), w);
+    store8(p, w);
+}
+__device__ __forceinline__ xyzz ld_xyzz(const uint32_t* p) {
+    xyzz r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { r.x.v[i] = p[i]; r.y.v[i] = p[9 + i]; r.zz.v[i] = p[18 + i]; r.zzz.v[i] = p[27 + i]; }
+    return r;
+}
+__device__ __forceinline__ void st_xyzz(uint32_t* p, const xyzz& r) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { p[i] = r.x.v[i]; p[9 + i] = r.y.v[i]; p[18 + i] = r.zz.v[i]; p[27 + i] = r.zzz.v[i]; }
+}
+__device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& a, int delta) {
+    xyzz r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.v[i] = __shfl_down(a.x.v[i], delta);
+        r.y.v[i] = __shfl_down(a.y.v[i], delta);
+        r.zz.v[i] = __shfl_down(a.zz.v[i], delta);
+        r.zzz.v[i] = __shfl_down(a.zzz.v[i], delta);
+    }
+    return r;
+}
+
+}  // namespace plk

@@ -1,0 +1,246 @@
+// BN254 field arithmetic for gfx950: nine 29-bit limbs, Montgomery radix 2^261.
+//
+// Why 29-bit limbs: on MI355X v_mad_u64_u32 issues at the same rate as a 64-bit add, so the cost of
+// a modular product is its instruction count.  With 29-bit limbs every column of the schoolbook
+// product (at most 9 + 9 partial products of < 2^60) fits one 64-bit accumulator: a column is a
+// pure chain of v_mad_u64_u32 with no carry, compare or move instructions in between
+// (171 multiply-adds per product, against >500 instructions for 8x32-bit limbs).
+//
+// Representation.  fe.v[i] holds limb i (little endian, weight 2^(29 i)); limb 8 holds everything
+// from bit 232 upwards.  Values are kept lazily reduced; each routine states what it needs:
+//   "normalized" : limbs 0..7 < 2^29
+//   "bound k"    : value < k * p
+// mul() needs  limb(a) * limb(b) <= 2^60.6 for every pair of limbs  and  bound(a) * bound(b) <= 169,
+// and returns a normalized value with bound 2.
+//
+// Montgomery scale.  mul(a, b) = a * b * 2^-261 mod p.  Memory formats keep the usual arkworks form
+// x * 2^256 (eight 32-bit words); kernels pick their constants so the scale comes out right:
+//   mul(x*2^256, w*2^261) = x*w*2^256     (data times library constant keeps the data's form)
+//   mul(x*2^256, TO_RP)   = x*2^261       mul(x*2^261, TO_R) = x*2^256
+//   mul(x*2^256, RAW32)   = x             mul(x*2^261, RAW1) = x
+#pragma once
+#include <stdint.h>
+#include "constants29.h"
+
+#if defined(__HIPCC__)
+#define PLK_HD __host__ __device__ __forceinline__
+#else
+#define PLK_HD inline
+#endif
+
+namespace plk {
+
+constexpr uint32_t M29 = 0x1fffffffu;
+
+struct fe {
+    uint32_t v[9];
+};
+
+PLK_HD fe fe_zero() {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = 0;
+    return r;
+}
+PLK_HD fe fe_const(const uint32_t (&c)[9]) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = c[i];
+    return r;
+}
+PLK_HD bool fe_is_zero_limbs(const fe& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o |= a.v[i];
+    return o == 0;
+}
+
+// eight 32-bit words <-> nine 29-bit limbs (bit re-slicing only, no change of value)
+PLK_HD fe unpack(const uint32_t* w) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, j = bit / 32, o = bit % 32;
+        uint32_t x = w[j] >> o;
+        if (o + 29 > 32 && j + 1 < 8) x |= w[j + 1] << (32 - o);
+        r.v[i] = (i < 8) ? (x & M29) : x;
+    }
+    return r;
+}
+// requires normalized limbs and value < 2^256
+PLK_HD void pack(const fe& a, uint32_t* w) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int bit = 32 * j, i = bit / 29, o = bit % 29;
+        uint32_t x = a.v[i] >> o;
+        x |= a.v[i + 1] << (29 - o);
+        w[j] = x;
+    }
+}
+
+// a * b * 2^-261 mod p (see the header comment for operand requirements); result normalized, bound 2
+template <class F>
+PLK_HD fe mul(const fe& a, const fe& b) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        m[k] = ((uint32_t)acc * F::NINV) & M29;
+        acc += (uint64_t)m[k] * F::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        r.v[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+// a * a * 2^-261 mod p; cross products are computed once against the doubled operand
+template <class F>
+PLK_HD fe sqr(const fe& a) {
+    uint64_t acc = 0;
+    uint32_t m[9], d[9];
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = a.v[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        m[k] = ((uint32_t)acc * F::NINV) & M29;
+        acc += (uint64_t)m[k] * F::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        r.v[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+// limb-wise sum, no carry: limb and value bounds add
+PLK_HD fe add(const fe& a, const fe& b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+// carry propagation: afterwards limbs 0..7 < 2^29 (value unchanged)
+PLK_HD void norm(fe& a) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a.v[i + 1] += a.v[i] >> 29;
+        a.v[i] &= M29;
+    }
+}
+// a - b + k*p, limb-wise against a k*p whose low limbs are >= 2^29 - 1.
+// Needs b normalized with bound k; the result is NOT normalized (limbs < limb(a) + 2^30), bound = bound(a) + k.
+#define PLK_DEFINE_SUB(K)                                              \
+    template <class F>                                                 \
+    PLK_HD fe sub##K(const fe& a, const fe& b) {                       \
+        fe r;                                                          \
+        _Pragma("unroll") for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + F::SUB##K[i] - b.v[i]; \
+        return r;                                                      \
+    }
+PLK_DEFINE_SUB(2)
+PLK_DEFINE_SUB(4)
+PLK_DEFINE_SUB(8)
+PLK_DEFINE_SUB(16)
+PLK_DEFINE_SUB(32)
+#undef PLK_DEFINE_SUB
+
+// normalized value with bound 2  ->  canonical representative in [0, p)
+template <class F>
+PLK_HD fe reduce(const fe& a) {
+    fe d;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t t = a.v[i] - F::P[i] - borrow;
+        borrow = t >> 31;
+        d.v[i] = (i < 8) ? (t & M29) : t;
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+
+// exact test "a == 0 (mod p)" for a normalized value with bound 64.
+// a = k*p forces k = a[0] * p^-1 mod 2^29, so almost every non-multiple is rejected by one multiply.
+template <class F>
+PLK_HD bool is_zero_mod(const fe& a) {
+    const uint32_t k = (a.v[0] * F::PINV) & M29;
+    if (k >= 64) return false;
+    uint64_t c = 0;
+    bool eq = true;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        c += (uint64_t)k * F::P[i];
+        const uint32_t limb = (i < 8) ? ((uint32_t)c & M29) : (uint32_t)c;
+        eq = eq && (limb == a.v[i]);
+        c >>= 29;
+    }
+    return eq;
+}
+
+// a^(p-2): inverse in the 2^261 Montgomery form (a = x*2^261 -> x^-1 * 2^261); a normalized, bound 2
+template <class F>
+PLK_HD fe inv(const fe& a) {
+    // exponent p - 2 as four 64-bit words, reassembled from the 29-bit limbs of p
+    uint64_t e[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i;
+        e[bit / 64] |= (uint64_t)F::P[i] << (bit % 64);
+        if (bit % 64 > 35 && bit / 64 + 1 < 4) e[bit / 64 + 1] |= (uint64_t)F::P[i] >> (64 - bit % 64);
+    }
+    e[0] -= 2;
+    fe r = fe_const(F::ONE);
+    for (int i = 253; i >= 0; --i) {
+        r = sqr<F>(r);
+        const uint64_t w = (i >= 192) ? e[3] : (i >= 128) ? e[2] : (i >= 64) ? e[1] : e[0];
+        if ((w >> (i & 63)) & 1) r = mul<F>(r, a);
+    }
+    return r;
+}
+
+// memory (x*2^256, eight words, canonical) -> limbs, same value
+PLK_HD fe load_fe(const uint32_t* p) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = p[i];
+    return unpack(w);
+}
+// normalized value with bound 2 -> canonical eight words
+template <class F>
+PLK_HD void store_fe(const fe& a, uint32_t* p) {
+    uint32_t w[8];
+    pack(reduce<F>(a), w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = w[i];
+}
+
+}  // namespace plk

@@ -1,0 +1,26 @@
+// Internal entry points shared between the translation units of libplonk_hip.
+#pragma once
+#include "common.cuh"
+#include "host_math.hpp"
+
+namespace plk {
+
+// msm.hip
+int32_t msm_acquire_slot(plk_ctx* ctx, int* out);
+int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind);
+int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);
+void slot_destroy(MsmSlot& s);
+
+// ntt.hip
+int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data_dev, uint32_t log_n, bool inverse, const uint64_t* coset_gen);
+int32_t ntt_twiddles(plk_ctx* ctx, uint32_t log_n, const uint32_t** out);   // w^i, i < n/2 (x*2^261 words); n >= 2
+void ntt_release(plk_ctx* ctx);
+
+// poly.hip
+// Suffix Horner scan on stream st:  h_i = sum_{k>=i} c_k zeta^(k-i).  Writes scale*h_i for i = 1..len-1 to q_out[i-1]
+// (skipped when q_out is null) and h_0 (unscaled) to h0_out (8 words, canonical).  work: >= division_work_words(len) words.
+int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs_dev, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
+                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work);
+uint64_t division_work_words(uint64_t len);
+
+}  // namespace plk

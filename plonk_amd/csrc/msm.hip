@@ -1,0 +1,514 @@
+// Pippenger MSM over BN254 G1 for gfx950, and the SRS tables it runs on.
+//
+// Layout.  The SRS is resident as MSM_WINDOWS tables T[j][i] = 2^(16 j) * P_i (affine, 64 B per point,
+// coordinates in the 2^261 Montgomery form of fp29.cuh).  With one table per window all windows share a
+// single set of 2^15 buckets:  sum_i s_i P_i = sum_k k * B_k,  B_k = sum of +-T[j][i] over all (i, j)
+// whose signed 16-bit digit has magnitude k.
+//
+// Pipeline of one MSM (all on one stream, several MSMs in flight on different streams):
+//   count     : per-block bucket histogram of the digits in LDS (128 KiB)        -> counts[block][bucket]
+//   totals / scan / offsets : bucket sizes, bucket starts, per-(block, bucket) write cursors
+//   scatter   : second pass over the scalars, LDS cursors hand out slots          -> entries sorted by bucket
+//   accumulate: G lanes per bucket stride over the bucket's entries with mixed XYZZ additions, then a
+//               wavefront shuffle tree combines the G partial sums                -> bucket_sums
+//   marginals : sum_k k B_k is linear in the bits of k; the bucket index is cut into 4 bit-fields and the
+//               56 sums "all buckets whose field d equals v" come from one block-wide tree each
+//   host      : ~130 point additions and one inversion finish the job (a GPU lane needs ~6 us per point
+//               addition, a host core ~0.3 us, so the serial tail belongs on the host).
+#include "common.cuh"
+#include "host_math.hpp"
+#include "kernels.h"
+
+namespace plk {
+
+// ------------------------------------------------------------------------------------------ scalars -> digits
+// scalar in memory: x * 2^256, canonical.  Returns 16 signed digits d_j in [-2^15+1, 2^15] with x = sum d_j 2^(16 j).
+__device__ __forceinline__ void scalar_digits(const uint32_t* sp, int32_t* d) {
+    const fe s = reduce<FrP>(mul<FrP>(ld_fe(sp), fe_const(FrP::RAW32)));
+    uint32_t w[8];
+    pack(s, w);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < MSM_WINDOWS; ++j) {
+        uint32_t raw = ((w[j >> 1] >> (16 * (j & 1))) & 0xffffu) + carry;
+        carry = raw > 0x8000u ? 1u : 0u;
+        d[j] = (int32_t)raw - (int32_t)(carry << 16);
+    }
+}
+__device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint32_t idx, uint32_t* table_index) {
+    if (idx < segs.s[0].count) {
+        *table_index = segs.s[0].table_off + idx;
+        return segs.s[0].scalars + 8ull * idx;
+    }
+    idx -= segs.s[0].count;
+    *table_index = segs.s[1].table_off + idx;
+    return segs.s[1].scalars + 8ull * idx;
+}
+
+__global__ void __launch_bounds__(1024) k_msm_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[MSM_BUCKETS];
+    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * chunk;
+    const uint32_t hi = min(lo + chunk, segs.total);
+    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += 1024) {
+        uint32_t ti;
+        const uint32_t* sp = seg_scalar(segs, idx, &ti);
+        int32_t d[MSM_WINDOWS];
+        scalar_digits(sp, d);
+#pragma unroll
+        for (int j = 0; j < MSM_WINDOWS; ++j)
+            if (d[j] != 0) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = counts + (size_t)blockIdx.x * MSM_BUCKETS;
+    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += 1024) row[i] = hist[i];
+}
+
+__global__ void __launch_bounds__(256) k_msm_totals(const uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ totals) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < nblocks; ++k) s += counts[(size_t)k * MSM_BUCKETS + b];
+    totals[b] = s;
+}
+// exclusive scan of MSM_BUCKETS totals by one block of 1024 threads (32 per thread)
+__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bucket_start) {
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v[32], s = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { v[i] = totals[t * 32 + i]; s += v[i]; }
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += x; }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wave; ++k) base += wave_sum[k];
+    uint32_t run = base + incl - s;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { bucket_start[t * 32 + i] = run; run += v[i]; }
+    if (t == 1023) bucket_start[MSM_BUCKETS] = run;
+}
+__global__ void __launch_bounds__(256) k_msm_offsets(uint32_t* __restrict__ counts, uint32_t nblocks, const uint32_t* __restrict__ bucket_start) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    uint32_t run = bucket_start[b];
+    for (uint32_t k = 0; k < nblocks; ++k) {
+        const size_t at = (size_t)k * MSM_BUCKETS + b;
+        const uint32_t c = counts[at];
+        counts[at] = run;
+        run += c;
+    }
+}
+__global__ void __launch_bounds__(1024) k_msm_scatter(MsmSegs segs, uint32_t chunk, const uint32_t* __restrict__ offsets, uint32_t table_stride,
+                                                      uint32_t* __restrict__ entries) {
+    __shared__ uint32_t cursor[MSM_BUCKETS];
+    const uint32_t* row = offsets + (size_t)blockIdx.x * MSM_BUCKETS;
+    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += 1024) cursor[i] = row[i];
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * chunk;
+    const uint32_t hi = min(lo + chunk, segs.total);
+    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += 1024) {
+        uint32_t ti;
+        const uint32_t* sp = seg_scalar(segs, idx, &ti);
+        int32_t d[MSM_WINDOWS];
+        scalar_digits(sp, d);
+#pragma unroll
+        for (int j = 0; j < MSM_WINDOWS; ++j) {
+            if (d[j] == 0) continue;
+            const uint32_t neg = d[j] < 0 ? 1u : 0u;
+            const uint32_t slot = atomicAdd(&cursor[(neg ? -d[j] : d[j]) - 1], 1u);
+            entries[slot] = (neg << 31) | ((uint32_t)j * table_stride + ti);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ buckets
+// 2^log_g lanes per bucket; lane g takes entries g, g + G, ...; lanes of one bucket are adjacent in a wavefront.
+__global__ void __launch_bounds__(256) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ bucket_start,
+                                                        const uint32_t* __restrict__ tables, uint32_t log_g, uint32_t* __restrict__ bucket_sums) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t G = 1u << log_g, b = t >> log_g, g = t & (G - 1);
+    const uint32_t start = bucket_start[b], end = bucket_start[b + 1];
+    xyzz acc = xyzz_inf();
+    uint32_t e = start + g;
+    uint32_t enc = e < end ? entries[e] : 0;
+    while (e < end) {
+        const uint32_t* p = tables + (size_t)(enc & 0x7fffffffu) * 16;
+        uint32_t wx[8], wy[8];
+        load8(p, wx);
+        load8(p + 8, wy);
+        const uint32_t neg = enc >> 31;
+        e += G;
+        if (e < end) enc = entries[e];
+        aff q;
+        q.x = unpack(wx);
+        q.y = unpack(wy);
+        if (neg) q.y = fq_neg_y(q.y);
+        xyzz_madd(acc, q);
+    }
+    for (uint32_t s = G >> 1; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, (int)s));
+    if (g == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
+}
+
+// One block per output: group d of the bucket index (bits [4d, 4d+4), the last group has 3 bits) equal to v.
+constexpr int MARG_THREADS = 512;
+__global__ void __launch_bounds__(MARG_THREADS) k_msm_marginals(const uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[MARG_THREADS / 64][XYZZ_WORDS];
+    const uint32_t o = blockIdx.x;
+    const uint32_t d = o < 48 ? o >> 4 : 3, v = o < 48 ? (o & 15) : o - 48;
+    const uint32_t shift = 4 * d, bits = d < 3 ? 4 : 3;
+    const uint32_t members = MSM_BUCKETS >> bits;
+    xyzz acc = xyzz_inf();
+    for (uint32_t m = threadIdx.x; m < members; m += MARG_THREADS) {
+        const uint32_t idx = ((m >> shift) << (shift + bits)) | (v << shift) | (m & ((1u << shift) - 1));
+        acc = xyzz_add(acc, ld_xyzz(bucket_sums + (size_t)idx * XYZZ_WORDS));
+    }
+    for (int s = 32; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) st_xyzz(part[wave], acc);
+    __syncthreads();
+    if (wave == 0) {
+        acc = lane < MARG_THREADS / 64 ? ld_xyzz(part[lane]) : xyzz_inf();
+        for (int s = MARG_THREADS / 128; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
+        if (lane == 0) {
+            uint32_t* dst = out + (size_t)o * 32;
+            const fe to_r = fe_const(FqP::TO_R);
+            st_fe<FqP>(dst, mul<FqP>(acc.x, to_r));
+            st_fe<FqP>(dst + 8, mul<FqP>(acc.y, to_r));
+            st_fe<FqP>(dst + 16, mul<FqP>(acc.zz, to_r));
+            st_fe<FqP>(dst + 24, mul<FqP>(acc.zzz, to_r));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ SRS tables
+// x*2^256 words -> canonical x*2^261 words
+__global__ void __launch_bounds__(256) k_fq_to_rp(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n_elems) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_elems) return;
+    st_fe<FqP>(out + 8 * i, mul<FqP>(ld_fe(in + 8 * i), fe_const(FqP::TO_RP)));
+}
+__global__ void __launch_bounds__(256) k_fq_to_r(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n_elems) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_elems) return;
+    st_fe<FqP>(out + 8 * i, mul<FqP>(ld_fe(in + 8 * i), fe_const(FqP::TO_R)));
+}
+__device__ __forceinline__ void store_affine_of(const xyzz& a, uint32_t* dst) {
+    const fe i = inv<FqP>(mul<FqP>(a.zz, a.zzz));
+    st_fe<FqP>(dst, mul<FqP>(a.x, mul<FqP>(i, a.zzz)));
+    st_fe<FqP>(dst + 8, mul<FqP>(a.y, mul<FqP>(i, a.zz)));
+}
+// next[i] = 2^16 * prev[i]
+__global__ void __launch_bounds__(256) k_table_next(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    xyzz a = xyzz_dbl_affine(load_aff(prev + 16 * i));
+    for (int k = 1; k < MSM_C; ++k) a = xyzz_dbl(a);
+    store_affine_of(a, next + 16 * i);
+}
+// dst[i] = scale * tau^(first + i) * G through 8-bit fixed-base windows of G: gt[w][d] = d * 2^(8 w) * G.
+// tau_pow2[k] = tau^(2^k), scale: x*2^256 words.
+__global__ void __launch_bounds__(256) k_srs_generate(const uint32_t* __restrict__ gt, const uint32_t* __restrict__ tau_pow2, const uint32_t* __restrict__ scale,
+                                                      uint64_t first, uint64_t count, uint32_t* __restrict__ dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const fe to_rp = fe_const(FrP::TO_RP);
+    fe s = ld_fe(scale);
+    const uint64_t e = first + i;
+    for (int k = 0; k < 40; ++k)
+        if ((e >> k) & 1) s = mul<FrP>(s, mul<FrP>(ld_fe(tau_pow2 + 8 * k), to_rp));
+    uint32_t w[8];
+    pack(reduce<FrP>(mul<FrP>(s, fe_const(FrP::RAW32))), w);
+    xyzz acc = xyzz_inf();
+    for (int j = 0; j < 32; ++j) {
+        const uint32_t d = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        if (d) xyzz_madd(acc, load_aff(gt + ((size_t)j * 256 + d) * 16));
+    }
+    store_affine_of(acc, dst + 16 * i);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
+    if (s.stream) return PLK_OK;
+    PLK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    PLK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    PLK_HIP(hipMalloc(&s.counts, (size_t)MSM_MAX_BLOCKS * MSM_BUCKETS * 4));
+    PLK_HIP(hipMalloc(&s.totals, (size_t)MSM_BUCKETS * 4));
+    PLK_HIP(hipMalloc(&s.bucket_start, (size_t)(MSM_BUCKETS + 1) * 4));
+    PLK_HIP(hipMalloc(&s.bucket_sums, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
+    PLK_HIP(hipMalloc(&s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4));
+    PLK_HIP(hipHostMalloc(&s.marg_host, (size_t)MSM_MARGINALS * 32 * 4, hipHostMallocDefault));
+    PLK_HIP(hipMalloc(&s.blind_dev, 64 * 4));
+    PLK_HIP(hipHostMalloc(&s.blind_host, 64 * 4, hipHostMallocDefault));
+    PLK_HIP(hipMalloc(&s.res_dev, 64 * 4));
+    PLK_HIP(hipHostMalloc(&s.res_host, 64 * 4, hipHostMallocDefault));
+    return PLK_OK;
+}
+void slot_destroy(MsmSlot& s) {
+    if (!s.stream) return;
+    hipStreamSynchronize(s.stream);
+    hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.marg_dev);
+    hipHostFree(s.marg_host); hipFree(s.blind_dev); hipHostFree(s.blind_host); hipFree(s.scal_dev); hipFree(s.chain_dev);
+    hipFree(s.res_dev); hipHostFree(s.res_host);
+    hipEventDestroy(s.done); hipStreamDestroy(s.stream);
+    s = MsmSlot();
+}
+
+int32_t msm_acquire_slot(plk_ctx* ctx, int* out) {
+    for (int k = 0; k < MSM_SLOTS; ++k) {
+        const int i = (ctx->next_slot + k) % MSM_SLOTS;
+        if (!ctx->slot[i].busy) {
+            PLK_TRY(slot_init(ctx, ctx->slot[i]));
+            ctx->next_slot = (i + 1) % MSM_SLOTS;
+            *out = i;
+            return PLK_OK;
+        }
+    }
+    ctx->err = "all MSM slots are busy: end an open ticket first";
+    return PLK_ERR_INVALID_ARG;
+}
+
+// Restricts the global range [base_offset, base_offset + k) to this context's shard.
+static void clip_to_shard(const plk_ctx* ctx, const uint32_t* scalars, uint64_t k, uint64_t base_offset, MsmSeg* seg) {
+    uint64_t lo = base_offset, hi = base_offset + k;
+    const uint64_t slo = ctx->shard_first, shi = ctx->shard_first + ctx->shard_len;
+    if (lo < slo) lo = slo;
+    if (hi > shi) hi = shi;
+    if (hi <= lo) { seg->scalars = scalars; seg->count = 0; seg->table_off = 0; return; }
+    seg->scalars = scalars + 8 * (lo - base_offset);
+    seg->count = (uint32_t)(hi - lo);
+    seg->table_off = (uint32_t)(lo - slo);
+}
+
+// Enqueues one MSM on the slot's stream: main segment (device scalars over powers_of_g) plus, when n_blind > 0 and this
+// shard holds the gamma powers, n_blind scalars (already in slot.blind_dev) over powers_of_gamma_g.
+int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind) {
+    if (!ctx->tables) { ctx->err = "no SRS loaded"; return PLK_ERR_INVALID_ARG; }
+    if (base_offset + k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
+    MsmSegs segs;
+    clip_to_shard(ctx, scalars_dev, k, base_offset, &segs.s[0]);
+    segs.s[1].scalars = s.blind_dev;
+    segs.s[1].count = ctx->has_gamma ? n_blind : 0;
+    segs.s[1].table_off = (uint32_t)ctx->shard_len;
+    segs.nseg = 2;
+    segs.total = segs.s[0].count + segs.s[1].count;
+    const uint64_t max_entries = (uint64_t)segs.total * MSM_WINDOWS;
+    if (max_entries > s.entries_cap) {
+        PLK_HIP(hipStreamSynchronize(s.stream));
+        if (s.entries) PLK_HIP(hipFree(s.entries));
+        s.entries = nullptr; s.entries_cap = 0;
+        const uint64_t cap = max_entries + max_entries / 8 + 1024;
+        PLK_HIP(hipMalloc(&s.entries, cap * 4));
+        s.entries_cap = cap;
+    }
+    uint32_t nblocks = (segs.total + 4095) / 4096;
+    if (nblocks < 1) nblocks = 1;
+    if (nblocks > MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
+    const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
+    hipStream_t st = s.stream;
+    prof_begin(ctx, st, "msm_sort");
+    hipLaunchKernelGGL(k_msm_count, dim3(nblocks), dim3(1024), 0, st, segs, chunk, s.counts);
+    hipLaunchKernelGGL(k_msm_totals, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.totals);
+    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, s.totals, s.bucket_start);
+    hipLaunchKernelGGL(k_msm_offsets, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.bucket_start);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks), dim3(1024), 0, st, segs, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries);
+    prof_end(ctx, st);
+    // lanes per bucket: about 64 entries per lane, at least 8 lanes so that the launch fills the chip
+    const uint64_t avg = max_entries / MSM_BUCKETS;
+    uint32_t log_g = 3;
+    while (log_g < 6 && (avg >> log_g) > 64) ++log_g;
+    prof_begin(ctx, st, "msm_accumulate");
+    hipLaunchKernelGGL(k_msm_accumulate, dim3((MSM_BUCKETS << log_g) / 256), dim3(256), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums);
+    prof_end(ctx, st);
+    prof_begin(ctx, st, "msm_reduce");
+    hipLaunchKernelGGL(k_msm_marginals, dim3(MSM_MARGINALS), dim3(MARG_THREADS), 0, st, s.bucket_sums, s.marg_dev);
+    prof_end(ctx, st);
+    PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
+// Host tail: sum_k k*B_k from the 56 marginal sums.  weight of bucket index idx is idx + 1.
+void msm_host_tail(const uint32_t* marg, host::pt* out) {
+    using namespace host;
+    const uint64_t* m = reinterpret_cast<const uint64_t*>(marg);
+    auto M = [&](int o) { return pt_load(m + 16 * o); };
+    pt total = pt_inf();
+    for (int v = 0; v < 16; ++v) total = pt_add(total, M(v));          // sum of all buckets (the "+1")
+    pt acc = pt_inf();
+    for (int d = 3; d >= 0; --d) {
+        const int nv = d < 3 ? 16 : 8, base = d < 3 ? 16 * d : 48;
+        pt run = pt_inf(), s = pt_inf();
+        for (int v = nv - 1; v >= 1; --v) { run = pt_add(run, M(base + v)); s = pt_add(s, run); }
+        if (d < 3) for (int k = 0; k < 4; ++k) acc = pt_dbl(acc);    // the group above sits 4 bits higher
+        acc = pt_add(acc, s);
+    }
+    *out = pt_add(acc, total);
+}
+
+int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out) {
+    PLK_HIP(hipStreamSynchronize(s.stream));
+    msm_host_tail(s.marg_host, out);
+    return PLK_OK;
+}
+
+// ---- SRS -------------------------------------------------------------------------------------------
+static int32_t srs_alloc(plk_ctx* ctx, uint64_t shard_first, uint64_t shard_len, uint64_t total_len) {
+    if (shard_first + shard_len > total_len || shard_len == 0 || shard_len + 3 >= (1ull << 27)) { ctx->err = "bad SRS shard"; return PLK_ERR_INVALID_ARG; }
+    if (ctx->tables) { PLK_HIP(hipDeviceSynchronize()); PLK_HIP(hipFree(ctx->tables)); ctx->tables = nullptr; }
+    ctx->srs_total = total_len; ctx->shard_first = shard_first; ctx->shard_len = shard_len;
+    ctx->has_gamma = shard_first == 0;
+    ctx->table_stride = shard_len + 3;
+    PLK_HIP(hipMalloc(&ctx->tables, (size_t)MSM_WINDOWS * ctx->table_stride * 64));
+    if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(ctx->tables + 16 * shard_len, 0, 3 * 64, ctx->stream));
+    return PLK_OK;
+}
+static int32_t srs_build_tables(plk_ctx* ctx) {
+    const uint64_t cnt = ctx->has_gamma ? ctx->table_stride : ctx->shard_len;
+    for (int j = 1; j < MSM_WINDOWS; ++j) {
+        const uint32_t* prev = ctx->tables + (size_t)(j - 1) * ctx->table_stride * 16;
+        uint32_t* next = ctx->tables + (size_t)j * ctx->table_stride * 16;
+        hipLaunchKernelGGL(k_table_next, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, cnt);
+    }
+    PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLK_OK;
+}
+
+}  // namespace plk
+
+using namespace plk;
+
+extern "C" int32_t plk_srs_load_shard(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t shard_first, uint64_t shard_len, uint64_t total_len,
+                                      const uint64_t* gamma_g_xy_host) {
+    if (!ctx || !g_xy_host) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(srs_alloc(ctx, shard_first, shard_len, total_len));
+    if (ctx->has_gamma && !gamma_g_xy_host) { ctx->err = "the shard holding index 0 needs the gamma powers"; return PLK_ERR_INVALID_ARG; }
+    const uint64_t cnt = ctx->has_gamma ? shard_len + 3 : shard_len;
+    uint32_t* staging = nullptr;
+    PLK_HIP(hipMalloc(&staging, cnt * 64));
+    PLK_HIP(hipMemcpyAsync(staging, g_xy_host, shard_len * 64, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->has_gamma) PLK_HIP(hipMemcpyAsync(staging + 16 * shard_len, gamma_g_xy_host, 3 * 64, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_fq_to_rp, dim3((unsigned)((cnt * 2 + 255) / 256)), dim3(256), 0, ctx->stream, staging, ctx->tables, cnt * 2);
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    PLK_HIP(hipFree(staging));
+    return srs_build_tables(ctx);
+}
+extern "C" int32_t plk_srs_load(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t len, const uint64_t* gamma_g_xy_host) {
+    return plk_srs_load_shard(ctx, g_xy_host, 0, len, len, gamma_g_xy_host);
+}
+
+extern "C" int32_t plk_srs_generate_shard(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t shard_first, uint64_t shard_len,
+                                          uint64_t total_len) {
+    if (!ctx || !tau || !gscal) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(srs_alloc(ctx, shard_first, shard_len, total_len));
+    using namespace host;
+    // fixed-base table of the generator: gt[w][d] = d * 2^(8w) * G, affine, x*2^256 form on the host
+    std::vector<uint64_t> gt((size_t)32 * 256 * 8, 0);
+    {
+        const uint64_t gx[4] = {1, 0, 0, 0}, gy[4] = {2, 0, 0, 0};
+        uint64_t gen[8];
+        el x = from_canonical(FQ, gx), y = from_canonical(FQ, gy);
+        memcpy(gen, x.v, 32); memcpy(gen + 4, y.v, 32);
+        pt base = pt_from_affine(gen);
+        for (int w = 0; w < 32; ++w) {
+            pt acc = pt_inf();
+            for (int d = 1; d < 256; ++d) {
+                acc = pt_add(acc, base);
+                int32_t inf;
+                pt_to_affine(acc, &gt[((size_t)w * 256 + d) * 8], &inf);
+            }
+            for (int k = 0; k < 8; ++k) base = pt_dbl(base);
+        }
+    }
+    std::vector<uint64_t> tp(40 * 4);
+    {
+        el t = el_load(tau);
+        for (int k = 0; k < 40; ++k) { memcpy(&tp[4 * k], t.v, 32); t = mul(FR, t, t); }
+    }
+    uint32_t *gt_dev = nullptr, *gt_rp = nullptr, *tp_dev = nullptr, *sc_dev = nullptr;
+    PLK_HIP(hipMalloc(&gt_dev, gt.size() * 8));
+    PLK_HIP(hipMalloc(&gt_rp, gt.size() * 8));
+    PLK_HIP(hipMalloc(&tp_dev, tp.size() * 8));
+    PLK_HIP(hipMalloc(&sc_dev, 64));
+    PLK_HIP(hipMemcpy(gt_dev, gt.data(), gt.size() * 8, hipMemcpyHostToDevice));
+    PLK_HIP(hipMemcpy(tp_dev, tp.data(), tp.size() * 8, hipMemcpyHostToDevice));
+    uint64_t sc[8];
+    memcpy(sc, FR.one, 32); memcpy(sc + 4, gscal, 32);
+    PLK_HIP(hipMemcpy(sc_dev, sc, 64, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fq_to_rp, dim3(32 * 256 * 2 / 256), dim3(256), 0, ctx->stream, gt_dev, gt_rp, (uint64_t)32 * 256 * 2);
+    hipLaunchKernelGGL(k_srs_generate, dim3((unsigned)((shard_len + 255) / 256)), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev, shard_first, shard_len, ctx->tables);
+    if (ctx->has_gamma)
+        hipLaunchKernelGGL(k_srs_generate, dim3(1), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev + 8, (uint64_t)0, (uint64_t)3, ctx->tables + 16 * shard_len);
+    PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(gt_dev); hipFree(gt_rp); hipFree(tp_dev); hipFree(sc_dev);
+    return srs_build_tables(ctx);
+}
+extern "C" int32_t plk_srs_generate(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t len) {
+    return plk_srs_generate_shard(ctx, tau, gscal, 0, len, len);
+}
+
+extern "C" int32_t plk_srs_read(plk_ctx* ctx, int32_t which, uint64_t first, uint64_t count, uint64_t* out_xy_host) {
+    if (!ctx || !ctx->tables || !out_xy_host) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    uint64_t off;
+    if (which == 0) {
+        if (first < ctx->shard_first || first + count > ctx->shard_first + ctx->shard_len) { ctx->err = "range outside this shard"; return PLK_ERR_INVALID_ARG; }
+        off = first - ctx->shard_first;
+    } else {
+        if (!ctx->has_gamma || first + count > 3) { ctx->err = "gamma powers not on this shard"; return PLK_ERR_INVALID_ARG; }
+        off = ctx->shard_len + first;
+    }
+    if (count == 0) return PLK_OK;
+    uint32_t* tmp = nullptr;
+    PLK_HIP(hipMalloc(&tmp, count * 64));
+    hipLaunchKernelGGL(k_fq_to_r, dim3((unsigned)((count * 2 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->tables + 16 * off, tmp, count * 2);
+    PLK_HIP(hipMemcpyAsync(out_xy_host, tmp, count * 64, hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    PLK_HIP(hipFree(tmp));
+    return PLK_OK;
+}
+
+// ---- MSM entry points ------------------------------------------------------------------------------
+extern "C" int32_t plk_msm_partial_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k, uint64_t base_offset, uint64_t out_xyzz[16]) {
+    if (!ctx || !out_xyzz || (k && !scalars_dev)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    int si;
+    PLK_TRY(msm_acquire_slot(ctx, &si));
+    MsmSlot& s = ctx->slot[si];
+    PLK_HIP(hipStreamSynchronize(ctx->stream));   // scalars may have been produced on the compute stream
+    PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)scalars_dev, k, base_offset, 0));
+    host::pt r;
+    PLK_TRY(msm_wait(ctx, s, &r));
+    prof_collect(ctx);
+    host::pt_store(r, out_xyzz);
+    return PLK_OK;
+}
+extern "C" int32_t plk_g1_sum_partials(const uint64_t* xyzz, uint64_t count, uint64_t out_xy[8], int32_t* out_is_inf) {
+    if (!out_xy || !out_is_inf || (count && !xyzz)) return PLK_ERR_INVALID_ARG;
+    host::pt acc = host::pt_inf();
+    for (uint64_t i = 0; i < count; ++i) acc = host::pt_add(acc, host::pt_load(xyzz + 16 * i));
+    host::pt_to_affine(acc, out_xy, out_is_inf);
+    return PLK_OK;
+}
+extern "C" int32_t plk_msm_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k, uint64_t base_offset, uint64_t out_xy[8], int32_t* out_is_inf) {
+    uint64_t part[16];
+    PLK_TRY(plk_msm_partial_dev(ctx, scalars_dev, k, base_offset, part));
+    return plk_g1_sum_partials(part, 1, out_xy, out_is_inf);
+}
+extern "C" int32_t plk_msm(plk_ctx* ctx, const uint64_t* scalars_host, uint64_t k, uint64_t base_offset, uint64_t out_xy[8], int32_t* out_is_inf) {
+    if (!ctx || (k && !scalars_host)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    if (k) {
+        PLK_HIP(hipMalloc(&d, k * 32));
+        PLK_HIP(hipMemcpy(d, scalars_host, k * 32, hipMemcpyHostToDevice));
+    }
+    const int32_t rc = plk_msm_dev(ctx, d, k, base_offset, out_xy, out_is_inf);
+    if (d) hipFree(d);
+    return rc;
+}

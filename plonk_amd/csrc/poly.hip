@@ -1,0 +1,494 @@
+// Pointwise, scan and reduction kernels of the prover rounds (all over BN254 Fr):
+//   grand product z (src/circuit.rs:491-544), gate + copy-constraint values for t (src/circuit.rs:343-379, 446-453),
+//   suffix-Horner scan = evaluation at zeta and synthetic division by (X - zeta) in one sweep
+//   (DensePolynomial::evaluate, src/prover.rs:266-274, and the witness polynomial of kzg10::open).
+// Elements in memory are x*2^256 (8 words); products against library constants in the 2^261 form keep that form.
+#include "common.cuh"
+#include "host_math.hpp"
+#include "kernels.h"
+
+namespace plk {
+
+struct W8 {
+    uint32_t w[8];
+};
+static W8 w8_of(const uint64_t* limbs) { W8 r; memcpy(r.w, limbs, 32); return r; }
+static W8 w8_of(const host::el& e) { return w8_of(e.v); }
+__device__ __forceinline__ fe fe_of(const W8& a) { return unpack(a.w); }
+// x*2^256 -> x*2^261
+__device__ __forceinline__ fe to_rp(const fe& a) { return mul<FrP>(a, fe_const(FrP::TO_RP)); }
+// normalized, bound 2 -> packed without the final subtraction (value < 2^255)
+__device__ __forceinline__ void st_lazy(uint32_t* p, const fe& a) {
+    uint32_t w[8];
+    pack(a, w);
+    store8(p, w);
+}
+
+// ------------------------------------------------------------------------------------------ element-wise (tests, microbenchmarks)
+template <class F>
+__global__ void __launch_bounds__(256) k_field_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const fe x = ld_fe(a + 8 * i), y = ld_fe(b + 8 * i);
+    fe r;
+    if (op == 0) { r = add(x, y); norm(r); r = mul<F>(r, fe_const(F::ONE)); }
+    else if (op == 1) { r = sub2<F>(x, y); norm(r); r = mul<F>(r, fe_const(F::ONE)); }
+    else r = mul<F>(mul<F>(x, fe_const(F::TO_RP)), y);
+    st_fe<F>(out + 8 * i, r);
+}
+
+// ------------------------------------------------------------------------------------------ suffix Horner scan
+constexpr int DIV_L = 32;   // elements per thread
+
+// S[t] = sum_{i in chunk t} c_i z^(i - t L)      (stored with bound 2)
+__global__ void __launch_bounds__(256) k_div_local(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, uint32_t* __restrict__ S) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t lo = t * DIV_L;
+    if (lo >= len) return;
+    const uint64_t hi = lo + DIV_L < len ? lo + DIV_L : len;
+    const fe z = to_rp(fe_of(zeta));
+    fe h = ld_fe(c + 8 * (hi - 1));
+    for (uint64_t i = hi - 1; i-- > lo;) h = add(ld_fe(c + 8 * i), mul<FrP>(h, z));
+    st_lazy(S + 8 * t, mul<FrP>(h, fe_const(FrP::ONE)));   // back to bound 2 so that every level starts alike
+}
+// h_i = c_i + z h_{i+1} inside chunk t, entered with carry[t + 1] (the suffix value at the start of the next chunk).
+// hs != null: hs[i] = h_i (lazy).  q_out != null: q_out[i - 1] = scale * h_i for i >= 1.  h0_out != null: h_0, canonical.
+__global__ void __launch_bounds__(256) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry, uint64_t n_carry,
+                                                   uint32_t* __restrict__ hs, uint32_t* __restrict__ q_out, W8 scale, uint32_t* __restrict__ h0_out) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t lo = t * DIV_L;
+    if (lo >= len) return;
+    const uint64_t hi = lo + DIV_L < len ? lo + DIV_L : len;
+    const fe z = to_rp(fe_of(zeta));
+    const fe sc = q_out ? to_rp(fe_of(scale)) : fe_zero();
+    fe h = (carry && t + 1 < n_carry) ? ld_fe(carry + 8 * (t + 1)) : fe_zero();
+    for (uint64_t i = hi; i-- > lo;) {
+        h = add(ld_fe(c + 8 * i), mul<FrP>(h, z));      // bound 4, limbs < 2^30
+        if (hs) { fe n = h; norm(n); st_lazy(hs + 8 * i, n); }
+        if (q_out && i >= 1) st_fe<FrP>(q_out + 8 * (i - 1), mul<FrP>(h, sc));
+        if (h0_out && i == 0) st_fe<FrP>(h0_out, mul<FrP>(h, fe_const(FrP::ONE)));
+    }
+}
+
+uint64_t division_work_words(uint64_t len) {
+    uint64_t words = 8, l = len;
+    while (l > 1) { l = (l + DIV_L - 1) / DIV_L; words += 2 * l * 8; }
+    return words + 64;
+}
+int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
+                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work) {
+    if (len == 0) {
+        if (h0_out) PLK_HIP(hipMemsetAsync(h0_out, 0, 32, st));
+        return PLK_OK;
+    }
+    // level k works at the point zeta^(L^k)
+    std::vector<uint64_t> lens{len};
+    while (lens.back() > 1) lens.push_back((lens.back() + DIV_L - 1) / DIV_L);
+    const int levels = (int)lens.size();           // arrays 0 .. levels-1, the last has one element
+    std::vector<host::el> zp(levels);
+    zp[0] = host::el_load(zeta);
+    for (int k = 1; k < levels; ++k) { host::el z = zp[k - 1]; for (int s = 0; s < 5; ++s) z = host::mul(host::FR, z, z); zp[k] = z; }
+    std::vector<uint32_t*> S(levels, nullptr), HS(levels, nullptr);
+    S[0] = const_cast<uint32_t*>(coeffs);
+    uint32_t* w = work;
+    for (int k = 1; k < levels; ++k) { S[k] = w; w += lens[k] * 8; HS[k] = w; w += lens[k] * 8; }
+    const W8 sc = w8_of(scale ? scale : host::FR.one);
+    prof_begin(ctx, st, "division");
+    for (int k = 0; k + 1 < levels; ++k) {
+        const uint64_t nthr = lens[k + 1];
+        hipLaunchKernelGGL(k_div_local, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, S[k], lens[k], w8_of(zp[k]), S[k + 1]);
+    }
+    for (int k = levels - 1; k >= 0; --k) {
+        const uint64_t nthr = (lens[k] + DIV_L - 1) / DIV_L;
+        const bool top = k + 1 >= levels;
+        hipLaunchKernelGGL(k_div_apply, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, S[k], lens[k], w8_of(zp[k]),
+                           top ? (const uint32_t*)nullptr : HS[k + 1], top ? 0 : lens[k + 1],
+                           k == 0 ? (uint32_t*)nullptr : HS[k], k == 0 ? q_out : (uint32_t*)nullptr, sc, k == 0 ? h0_out : (uint32_t*)nullptr);
+    }
+    prof_end(ctx, st);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ grand product
+// term = w + beta * idx + gamma in the 2^261 form (bound 6, normalized).  beta2 = beta * 2^522, gamma1 = gamma * 2^261.
+__device__ __forceinline__ fe perm_term(const fe& w_r, uint32_t idx, const fe& beta2, const fe& gamma1) {
+    fe j = fe_zero();
+    j.v[0] = idx;                                  // idx < 2^29
+    fe t = add(add(to_rp(w_r), mul<FrP>(beta2, j)), gamma1);
+    norm(t);
+    return t;
+}
+__global__ void __launch_bounds__(256) k_gp_terms(const uint32_t* __restrict__ wflat, const uint64_t* __restrict__ sigma, uint64_t n, W8 beta, W8 gamma,
+                                                  uint32_t* __restrict__ num, uint32_t* __restrict__ den, uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const fe beta2 = mul<FrP>(to_rp(fe_of(beta)), fe_const(FrP::R2)), gamma1 = to_rp(fe_of(gamma));
+    fe nu, de;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t j = 3 * i + k;
+        uint64_t sj = sigma[j];
+        if (sj >= 3 * n) { atomicOr(flag, 2u); sj = 0; }
+        const fe tn = perm_term(ld_fe(wflat + 8 * j), (uint32_t)j, beta2, gamma1);
+        const fe td = perm_term(ld_fe(wflat + 8 * sj), (uint32_t)sj, beta2, gamma1);
+        nu = k == 0 ? tn : mul<FrP>(nu, tn);
+        de = k == 0 ? td : mul<FrP>(de, td);
+    }
+    // after the loop nu, de are products (bound 2) in the 2^261 form
+    st_lazy(num + 8 * i, nu);
+    st_lazy(den + 8 * i, de);
+}
+
+// Inclusive multiplicative scan of 2^261-form values, 2048 per block (8 per thread); reverse scans run from the top index down.
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_BLOCK = 256 * SCAN_PER_THREAD;
+__global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data, uint64_t n, int reverse, uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t wave_tot[4][9];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    fe p[SCAN_PER_THREAD];
+    fe run = fe_const(FrP::ONE);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        const uint64_t i = base + k;
+        if (i < n) run = mul<FrP>(run, ld_fe(data + 8 * (reverse ? n - 1 - i : i)));
+        p[k] = run;
+    }
+    fe incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        fe other;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) other.v[q] = __shfl_up(incl.v[q], o);
+        const fe prod = mul<FrP>(other, incl);
+        if (lane >= (uint32_t)o) incl = prod;
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wave_tot[wave][q] = incl.v[q];
+    }
+    fe excl;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) excl.v[q] = __shfl_up(incl.v[q], 1);
+    if (lane == 0) excl = fe_const(FrP::ONE);
+    __syncthreads();
+    for (uint32_t v = 0; v < wave; ++v) {
+        fe wt;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wt.v[q] = wave_tot[v][q];
+        excl = mul<FrP>(wt, excl);
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        const uint64_t i = base + k;
+        if (i < n) st_lazy(data + 8 * (reverse ? n - 1 - i : i), mul<FrP>(excl, p[k]));
+    }
+    if (threadIdx.x == 255) st_lazy(block_tot + 8ull * blockIdx.x, mul<FrP>(excl, p[SCAN_PER_THREAD - 1]));
+}
+__global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ data, uint64_t n, int reverse, const uint32_t* __restrict__ block_incl) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t b = i / SCAN_BLOCK;
+    if (b == 0) return;
+    uint32_t* p = data + 8 * (reverse ? n - 1 - i : i);
+    st_lazy(p, mul<FrP>(ld_fe(block_incl + 8 * (b - 1)), ld_fe(p)));
+}
+// in-place inclusive scan; work must hold the block totals of every level (<= n/1024 elements in all)
+static int32_t scan_mul(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint64_t n, bool reverse, uint32_t* work) {
+    const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb), dim3(256), 0, st, data, n, reverse ? 1 : 0, work);
+    if (nb > 1) {
+        PLK_TRY(scan_mul(ctx, st, work, nb, false, work + 8 * nb));
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, n, reverse ? 1 : 0, work);
+    }
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+// z[0] = 1, z[i] = N_{i-1} * S_i / D for 0 < i < n, with N the prefix products of the numerators, S the suffix
+// products of the denominators, dinv = D^-1 * 2^256.
+__global__ void __launch_bounds__(256) k_gp_finish(const uint32_t* __restrict__ num_pre, const uint32_t* __restrict__ den_suf, uint64_t n, W8 dinv,
+                                                   uint32_t* __restrict__ z) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0) { st_fe<FrP>(z, mul<FrP>(fe_const(FrP::ONE), fe_const(FrP::TO_R))); return; }
+    st_fe<FrP>(z + 8 * i, mul<FrP>(mul<FrP>(ld_fe(num_pre + 8 * (i - 1)), ld_fe(den_suf + 8 * i)), fe_of(dinv)));
+}
+
+// ------------------------------------------------------------------------------------------ quotient numerator on H
+// vals[i] = q_add (a + b - c) + q_mul (a b - c) + [ z_i prod(w + beta (3i+k) + gamma) - z_{i+1} prod(w + beta sigma(3i+k) + gamma) ]
+// and in the last row  z_i prod / prod' - 1  (src/circuit.rs:370-379).
+__global__ void __launch_bounds__(256) k_quotient_vals(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
+                                                       const uint32_t* __restrict__ qa, const uint32_t* __restrict__ qm, const uint32_t* __restrict__ zv,
+                                                       const uint64_t* __restrict__ sigma, uint64_t n, W8 beta, W8 gamma, uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const fe beta2 = mul<FrP>(to_rp(fe_of(beta)), fe_const(FrP::R2)), gamma1 = to_rp(fe_of(gamma));
+    const fe w[3] = {ld_fe(a + 8 * i), ld_fe(b + 8 * i), ld_fe(c + 8 * i)};
+    // gate
+    fe s = add(w[0], w[1]);
+    s = sub2<FrP>(s, w[2]); norm(s);                                   // a + b - c, bound 4
+    fe ab = mul<FrP>(to_rp(w[0]), w[1]);
+    fe m = sub2<FrP>(ab, w[2]); norm(m);                               // a b - c, bound 4
+    fe gate = add(mul<FrP>(to_rp(ld_fe(qa + 8 * i)), s), mul<FrP>(to_rp(ld_fe(qm + 8 * i)), m));   // bound 4, limbs < 2^30
+    // copy constraint
+    fe lhs, rhs;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint64_t sj = sigma[3 * i + k];
+        if (sj >= 3 * n) { atomicOr(flag, 2u); sj = 0; }
+        const fe tl = perm_term(w[k], (uint32_t)(3 * i + k), beta2, gamma1);
+        const fe tr = perm_term(w[k], (uint32_t)sj, beta2, gamma1);
+        lhs = k == 0 ? tl : mul<FrP>(lhs, tl);
+        rhs = k == 0 ? tr : mul<FrP>(rhs, tr);
+    }
+    const fe zi = ld_fe(zv + 8 * i);
+    fe perm;
+    if (i + 1 < n) {
+        const fe l = mul<FrP>(lhs, zi), r = mul<FrP>(rhs, ld_fe(zv + 8 * (i + 1)));   // x*2^256 form
+        perm = sub2<FrP>(l, r);                                        // bound 4
+    } else {
+        // z lhs / rhs - 1 = (z lhs - rhs) / rhs: zero exactly when the numerator is, so the inversion is only paid on bad witnesses
+        const fe l = mul<FrP>(lhs, zi), r = mul<FrP>(rhs, fe_const(FrP::TO_R));
+        fe d = sub2<FrP>(l, r); norm(d);
+        if (is_zero_mod<FrP>(d)) perm = fe_zero();
+        else {
+            fe rr = rhs; // 2^261 form, bound 2
+            if (is_zero_mod<FrP>(rr)) { atomicOr(flag, 4u); perm = fe_zero(); }
+            else perm = mul<FrP>(inv<FrP>(rr), d);                     // (1/rhs)*2^261 times d*2^256 -> x*2^256
+        }
+    }
+    fe v = add(gate, perm);                                            // bound 8
+    norm(v);
+    const fe out = reduce<FrP>(mul<FrP>(v, fe_const(FrP::ONE)));
+    uint32_t wv[8];
+    pack(out, wv);
+    store8(vals + 8 * i, wv);
+}
+__global__ void __launch_bounds__(256) k_any_nonzero(const uint32_t* __restrict__ data, uint64_t n_words, uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = 0;
+    for (uint64_t k = i; k < n_words; k += (uint64_t)gridDim.x * 256) v |= data[k];
+    if (v) atomicOr(flag, 1u);
+}
+
+// ------------------------------------------------------------------------------------------ permutation polynomials
+// vals_id[i] = w^i, vals_sigma[i] = w^(sigma_pad(i)) on the domain of size 2^log_n4 (src/poly_utils.rs:18-25)
+__global__ void __launch_bounds__(256) k_perm_values(const uint64_t* __restrict__ sigma, uint64_t sigma_len, uint32_t log_n4, const uint32_t* __restrict__ W,
+                                                     uint32_t* __restrict__ vals_id, uint32_t* __restrict__ vals_sigma, uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t n4 = 1ull << log_n4;
+    if (i >= n4) return;
+    uint64_t s = i < sigma_len ? sigma[i] : i;
+    if (s >= n4) { atomicOr(flag, 2u); s = 0; }
+    const fe to_r = fe_const(FrP::TO_R);
+    const uint64_t e[2] = {i, s};
+    uint32_t* dst[2] = {vals_id, vals_sigma};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        uint64_t x = e[k];
+        const bool neg = x >= (n4 >> 1);
+        if (neg) x -= n4 >> 1;
+        fe y = mul<FrP>(ld_fe(W + 8 * x), to_r);
+        if (neg) { y = sub2<FrP>(fe_zero(), y); norm(y); }
+        st_fe<FrP>(dst[k] + 8 * i, y);
+    }
+}
+
+}  // namespace plk
+
+using namespace plk;
+
+// ================================================================================================ entry points
+extern "C" int32_t plk_field_op(plk_ctx* ctx, int32_t field, int32_t op, const uint64_t* a_host, const uint64_t* b_host, uint64_t* out_host, uint64_t n) {
+    if (!ctx || !a_host || !b_host || !out_host || op < 0 || op > 2) return PLK_ERR_INVALID_ARG;
+    if (n == 0) return PLK_OK;
+    PLK_HIP(hipSetDevice(ctx->device));
+    uint32_t *a, *b, *o;
+    PLK_HIP(hipMalloc(&a, n * 32)); PLK_HIP(hipMalloc(&b, n * 32)); PLK_HIP(hipMalloc(&o, n * 32));
+    PLK_HIP(hipMemcpy(a, a_host, n * 32, hipMemcpyHostToDevice));
+    PLK_HIP(hipMemcpy(b, b_host, n * 32, hipMemcpyHostToDevice));
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (field == 0) hipLaunchKernelGGL(k_field_op<FrP>, grid, dim3(256), 0, ctx->stream, op, a, b, o, n);
+    else hipLaunchKernelGGL(k_field_op<FqP>, grid, dim3(256), 0, ctx->stream, op, a, b, o, n);
+    PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    PLK_HIP(hipMemcpy(out_host, o, n * 32, hipMemcpyDeviceToHost));
+    hipFree(a); hipFree(b); hipFree(o);
+    return PLK_OK;
+}
+
+extern "C" int32_t plk_poly_eval_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], uint64_t out[4]) {
+    if (!ctx || !x || !out || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t words = division_work_words(len);
+    PLK_TRY(ensure_scratch(ctx, words * 4));
+    PLK_TRY(division_enqueue(ctx, ctx->stream, (const uint32_t*)coeffs_dev, len, x, nullptr, nullptr, ctx->scratch, ctx->scratch + 8));
+    PLK_HIP(hipMemcpyAsync(out, ctx->scratch, 32, hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    return PLK_OK;
+}
+extern "C" int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t x[4], uint64_t out[4]) {
+    if (!ctx || (len && !coeffs_host)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    if (len) { PLK_HIP(hipMalloc(&d, len * 32)); PLK_HIP(hipMemcpy(d, coeffs_host, len * 32, hipMemcpyHostToDevice)); }
+    const int32_t rc = plk_poly_eval_dev(ctx, d, len, x, out);
+    if (d) hipFree(d);
+    return rc;
+}
+
+static int32_t read_flag(plk_ctx* ctx, uint32_t* out) {
+    PLK_HIP(hipMemcpyAsync(ctx->flag_host, ctx->flag_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    *out = *ctx->flag_host;
+    return PLK_OK;
+}
+
+extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
+                                         const uint64_t gamma[4], void* z_coeffs_out_dev) {
+    if (!ctx || !witness_flat_dev || !sigma_dev || !beta || !gamma || !z_coeffs_out_dev || log_n > 26) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n;
+    hipStream_t st = ctx->stream;
+    // scratch: num[n], den[n], scan work (2 * n/1024 + slack), all 8-word elements
+    const uint64_t work_elems = 2 * (n / 1024 + 64);
+    PLK_TRY(ensure_scratch(ctx, (2 * n + work_elems) * 32));
+    uint32_t *num = ctx->scratch, *den = num + 8 * n, *work = den + 8 * n;
+    PLK_HIP(hipMemsetAsync(ctx->flag_dev, 0, 4, st));
+    prof_begin(ctx, st, "pointwise");
+    hipLaunchKernelGGL(k_gp_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)witness_flat_dev, (const uint64_t*)sigma_dev, n,
+                       w8_of(beta), w8_of(gamma), num, den, ctx->flag_dev);
+    PLK_TRY(scan_mul(ctx, st, num, n, false, work));
+    PLK_TRY(scan_mul(ctx, st, den, n, true, work));
+    prof_end(ctx, st);
+    // one inversion of the full denominator product on the host
+    uint64_t dtot[4];
+    PLK_HIP(hipMemcpyAsync(dtot, den, 32, hipMemcpyDeviceToHost, st));
+    uint32_t flag;
+    PLK_TRY(read_flag(ctx, &flag));
+    if (flag & 2u) { ctx->err = "sigma entry out of range"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
+    // dtot = D * 2^261 read as the 2^256 form of 32 D; its inverse times 32 is D^-1 * 2^256
+    host::el d = host::el_load(dtot);
+    while (host::geq(d.v, host::FR.p)) host::sub_inplace(d.v, host::FR.p);
+    if (host::is_zero(d)) { ctx->err = "grand product: denominator is zero"; return PLK_ERR_INVERSE_OF_ZERO; }
+    const host::el dinv = host::mul(host::FR, host::inv(host::FR, d), host::from_u64(host::FR, 32));
+    prof_begin(ctx, st, "pointwise");
+    hipLaunchKernelGGL(k_gp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, num, den, n, w8_of(dinv), (uint32_t*)z_coeffs_out_dev);
+    prof_end(ctx, st);
+    PLK_HIP(hipGetLastError());
+    PLK_TRY(ntt_run(ctx, st, (uint32_t*)z_coeffs_out_dev, log_n, true, nullptr));
+    PLK_HIP(hipStreamSynchronize(st));
+    prof_collect(ctx);
+    return PLK_OK;
+}
+extern "C" int32_t plk_grand_product(plk_ctx* ctx, const uint64_t* witness_flat_host, const uint64_t* sigma_host, uint32_t log_n, const uint64_t beta[4],
+                                     const uint64_t gamma[4], uint64_t* z_coeffs_out_host) {
+    if (!ctx || !witness_flat_host || !sigma_host || !z_coeffs_out_host || log_n > 26) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n;
+    void *w, *s, *z;
+    PLK_HIP(hipMalloc(&w, 3 * n * 32)); PLK_HIP(hipMalloc(&s, 3 * n * 8)); PLK_HIP(hipMalloc(&z, n * 32));
+    PLK_HIP(hipMemcpy(w, witness_flat_host, 3 * n * 32, hipMemcpyHostToDevice));
+    PLK_HIP(hipMemcpy(s, sigma_host, 3 * n * 8, hipMemcpyHostToDevice));
+    int32_t rc = plk_grand_product_dev(ctx, w, s, log_n, beta, gamma, z);
+    if (rc == PLK_OK && hipMemcpy(z_coeffs_out_host, z, n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
+    hipFree(w); hipFree(s); hipFree(z);
+    return rc;
+}
+
+extern "C" int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                                    const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev,
+                                    uint64_t* t_len) {
+    if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !beta || !gamma || !t_out_dev || !t_len || log_n > 26)
+        return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n;
+    hipStream_t st = ctx->stream;
+    uint32_t* t = (uint32_t*)t_out_dev;
+    PLK_HIP(hipMemsetAsync(ctx->flag_dev, 0, 4, st));
+    prof_begin(ctx, st, "pointwise");
+    hipLaunchKernelGGL(k_quotient_vals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)c,
+                       (const uint32_t*)q_add_vals, (const uint32_t*)q_mul_vals, (const uint32_t*)z_vals, (const uint64_t*)sigma, n, w8_of(beta), w8_of(gamma), t,
+                       ctx->flag_dev);
+    prof_end(ctx, st);
+    PLK_HIP(hipGetLastError());
+    // numerator in coefficient form: ifft(gate) + ifft(perm) + ifft(0) = ifft(gate + perm)
+    PLK_TRY(ntt_run(ctx, st, t, log_n, true, nullptr));
+    // divide_by_vanishing_poly on a numerator of degree < n: quotient 0, remainder = the numerator, which must vanish
+    hipLaunchKernelGGL(k_any_nonzero, dim3(256), dim3(256), 0, st, t, n * 8, ctx->flag_dev);
+    uint32_t flag;
+    PLK_TRY(read_flag(ctx, &flag));
+    prof_collect(ctx);
+    if (flag & 2u) { ctx->err = "sigma entry out of range"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
+    if (flag & 4u) { ctx->err = "permutation constraint: inverse of zero"; return PLK_ERR_INVERSE_OF_ZERO; }
+    if (flag & 1u) { ctx->err = "t(X) not divisible by Z_H(X)"; return PLK_ERR_NOT_DIVISIBLE; }
+    *t_len = 0;
+    return PLK_OK;
+}
+extern "C" int32_t plk_quotient(plk_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* q_add_vals, const uint64_t* q_mul_vals,
+                                const uint64_t* z_vals, const uint64_t* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                                uint64_t* t_out_host, uint64_t* t_len) {
+    if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !t_out_host || log_n > 26) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n;
+    const uint64_t* src[6] = {a, b, c, q_add_vals, q_mul_vals, z_vals};
+    void* d[6]; void *s, *t;
+    for (int i = 0; i < 6; ++i) { PLK_HIP(hipMalloc(&d[i], n * 32)); PLK_HIP(hipMemcpy(d[i], src[i], n * 32, hipMemcpyHostToDevice)); }
+    PLK_HIP(hipMalloc(&s, 3 * n * 8)); PLK_HIP(hipMemcpy(s, sigma, 3 * n * 8, hipMemcpyHostToDevice));
+    PLK_HIP(hipMalloc(&t, n * 32));
+    int32_t rc = plk_quotient_dev(ctx, d[0], d[1], d[2], d[3], d[4], d[5], s, log_n, beta, gamma, t, t_len);
+    if (rc == PLK_OK && hipMemcpy(t_out_host, t, n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
+    for (int i = 0; i < 6; ++i) hipFree(d[i]);
+    hipFree(s); hipFree(t);
+    return rc;
+}
+
+extern "C" int32_t plk_interpolate_permutation_dev(plk_ctx* ctx, const void* sigma_dev, uint64_t sigma_len, uint32_t log_n4, void* s_id_out_dev,
+                                                   void* s_sigma_out_dev) {
+    if (!ctx || (sigma_len && !sigma_dev) || !s_id_out_dev || !s_sigma_out_dev || log_n4 < 1 || log_n4 > 27 || sigma_len > (1ull << log_n4))
+        return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n4 = 1ull << log_n4;
+    hipStream_t st = ctx->stream;
+    const uint32_t* W;
+    PLK_TRY(ntt_twiddles(ctx, log_n4, &W));
+    PLK_HIP(hipMemsetAsync(ctx->flag_dev, 0, 4, st));
+    hipLaunchKernelGGL(k_perm_values, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const uint64_t*)sigma_dev, sigma_len, log_n4, W,
+                       (uint32_t*)s_id_out_dev, (uint32_t*)s_sigma_out_dev, ctx->flag_dev);
+    PLK_HIP(hipGetLastError());
+    PLK_TRY(ntt_run(ctx, st, (uint32_t*)s_id_out_dev, log_n4, true, nullptr));
+    PLK_TRY(ntt_run(ctx, st, (uint32_t*)s_sigma_out_dev, log_n4, true, nullptr));
+    uint32_t flag;
+    PLK_TRY(read_flag(ctx, &flag));
+    prof_collect(ctx);
+    if (flag & 2u) { ctx->err = "sigma entry outside the permutation domain"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
+    return PLK_OK;
+}
+extern "C" int32_t plk_interpolate_permutation(plk_ctx* ctx, const uint64_t* sigma_host, uint64_t sigma_len, uint32_t log_n4, uint64_t* s_id_out_host,
+                                               uint64_t* s_sigma_out_host) {
+    if (!ctx || !s_id_out_host || !s_sigma_out_host || log_n4 < 1 || log_n4 > 27) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n4 = 1ull << log_n4;
+    void *s = nullptr, *o0, *o1;
+    if (sigma_len) { PLK_HIP(hipMalloc(&s, sigma_len * 8)); PLK_HIP(hipMemcpy(s, sigma_host, sigma_len * 8, hipMemcpyHostToDevice)); }
+    PLK_HIP(hipMalloc(&o0, n4 * 32)); PLK_HIP(hipMalloc(&o1, n4 * 32));
+    int32_t rc = plk_interpolate_permutation_dev(ctx, s, sigma_len, log_n4, o0, o1);
+    if (rc == PLK_OK && (hipMemcpy(s_id_out_host, o0, n4 * 32, hipMemcpyDeviceToHost) != hipSuccess ||
+                         hipMemcpy(s_sigma_out_host, o1, n4 * 32, hipMemcpyDeviceToHost) != hipSuccess)) rc = PLK_ERR_HIP;
+    if (s) hipFree(s);
+    hipFree(o0); hipFree(o1);
+    return rc;
+}
+extern "C" int32_t plk_interpolate_selector(plk_ctx* ctx, const uint64_t* values_host, uint64_t len, uint64_t* coeffs_out_host, uint32_t* log_n_out) {
+    if (!ctx || !values_host || !coeffs_out_host || !log_n_out || len == 0) return PLK_ERR_INVALID_ARG;
+    uint32_t log_n = 0;
+    while ((1ull << log_n) < len) ++log_n;
+    const uint64_t n = 1ull << log_n;
+    memcpy(coeffs_out_host, values_host, len * 32);
+    memset(coeffs_out_host + 4 * len, 0, (n - len) * 32);
+    *log_n_out = log_n;
+    return plk_ntt(ctx, coeffs_out_host, log_n, 1, nullptr);
+}

@@ -1,0 +1,281 @@
+"""ctypes binding of libplonk_hip.so (the C ABI declared in include/plonk_hip.h).
+
+Field elements travel as numpy uint64 arrays of shape (n, 4) in Montgomery form (x * 2^256), points as (n, 8)
+x||y.  There is no CPU fallback: if the shared library is missing or no GPU is visible every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplonk_hip.so")
+
+STATUS = {
+    0: "PLK_OK", 1: "PLK_ERR_INVALID_ARG", 2: "PLK_ERR_HIP", 3: "PLK_ERR_NO_DEVICE", 4: "PLK_ERR_SRS_TOO_SHORT",
+    5: "PLK_ERR_NOT_DIVISIBLE", 6: "PLK_ERR_INVERSE_OF_ZERO", 7: "PLK_ERR_INDEX_OUT_OF_RANGE", 8: "PLK_ERR_ALLOC",
+}
+# every symbol include/plonk_hip.h declares
+EXPORTS = [
+    "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync",
+    "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_read",
+    "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev",
+    "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
+    "plk_grand_product", "plk_grand_product_dev", "plk_quotient", "plk_quotient_dev", "plk_poly_eval", "plk_poly_eval_dev",
+    "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
+    "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
+    "plk_profile_get",
+]
+
+
+class PlonkHipError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        self.status = STATUS.get(code, str(code))
+        super().__init__(f"{self.status}: {detail}" if detail else self.status)
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libplonk_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C plonk_amd/csrc` (no CPU fallback exists)")
+        _lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(_lib, name)
+        _lib.plk_last_error.restype = C.c_char_p
+        _lib.plk_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _fr(a, shape=(-1, 4)):
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(shape)
+
+
+def _vp(x):
+    return C.c_void_p(x if x else None)
+
+
+class Context:
+    """One plk_ctx on one GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.plk_create(C.c_int32(device), C.byref(h))
+        if rc != 0:
+            raise PlonkHipError(rc, "plk_create failed (is a GPU visible?)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.plk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PlonkHipError(rc, (self.lib.plk_last_error(self.h) or b"").decode())
+
+    # ---- memory
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._ck(self.lib.plk_malloc(self.h, C.c_uint64(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, dptr: int):
+        self._ck(self.lib.plk_free(self.h, _vp(dptr)))
+
+    def upload(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        d = self.malloc(max(arr.nbytes, 32))
+        if arr.nbytes:
+            self._ck(self.lib.plk_upload(self.h, _vp(d), _ptr(arr), C.c_uint64(arr.nbytes)))
+        return d
+
+    def upload_into(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.lib.plk_upload(self.h, _vp(dptr), _ptr(arr), C.c_uint64(arr.nbytes)))
+
+    def download(self, dptr: int, shape, dtype=np.uint64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes:
+            self._ck(self.lib.plk_download(self.h, _ptr(out), _vp(dptr), C.c_uint64(out.nbytes)))
+        return out
+
+    def sync(self):
+        self._ck(self.lib.plk_sync(self.h))
+
+    # ---- SRS
+    def srs_load(self, g_xy, gamma_g_xy, shard_first=0, total_len=None):
+        g = _fr(g_xy, (-1, 8))
+        gg = _fr(gamma_g_xy, (-1, 8)) if gamma_g_xy is not None else None
+        total = len(g) if total_len is None else total_len
+        self._ck(self.lib.plk_srs_load_shard(self.h, _ptr(g), C.c_uint64(shard_first), C.c_uint64(len(g)), C.c_uint64(total), _ptr(gg)))
+
+    def srs_generate(self, tau, gscal, length, shard_first=0, shard_len=None):
+        sl = length if shard_len is None else shard_len
+        self._ck(self.lib.plk_srs_generate_shard(self.h, _ptr(_fr(tau, (4,))), _ptr(_fr(gscal, (4,))), C.c_uint64(shard_first), C.c_uint64(sl),
+                                                 C.c_uint64(length)))
+
+    def srs_read(self, which, first, count):
+        out = np.empty((count, 8), dtype=np.uint64)
+        self._ck(self.lib.plk_srs_read(self.h, C.c_int32(which), C.c_uint64(first), C.c_uint64(count), _ptr(out)))
+        return out
+
+    # ---- MSM
+    def msm(self, scalars, base_offset=0):
+        s = _fr(scalars)
+        out = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)
+        self._ck(self.lib.plk_msm(self.h, _ptr(s) if len(s) else None, C.c_uint64(len(s)), C.c_uint64(base_offset), _ptr(out), C.byref(inf)))
+        return out, inf.value
+
+    def msm_dev(self, d_scalars, k, base_offset=0):
+        out = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)
+        self._ck(self.lib.plk_msm_dev(self.h, _vp(d_scalars), C.c_uint64(k), C.c_uint64(base_offset), _ptr(out), C.byref(inf)))
+        return out, inf.value
+
+    def msm_partial_dev(self, d_scalars, k, base_offset=0):
+        out = np.empty(16, dtype=np.uint64)
+        self._ck(self.lib.plk_msm_partial_dev(self.h, _vp(d_scalars), C.c_uint64(k), C.c_uint64(base_offset), _ptr(out)))
+        return out
+
+    def sum_partials(self, parts):
+        p = _fr(parts, (-1, 16))
+        out = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)
+        self._ck(self.lib.plk_g1_sum_partials(_ptr(p), C.c_uint64(len(p)), _ptr(out), C.byref(inf)))
+        return out, inf.value
+
+    # ---- NTT
+    def ntt(self, data, inverse=False, coset=None):
+        a = _fr(data).copy()
+        log_n = (len(a) - 1).bit_length()
+        assert 1 << log_n == len(a)
+        self._ck(self.lib.plk_ntt(self.h, _ptr(a), C.c_uint32(log_n), C.c_int32(int(inverse)), _ptr(_fr(coset, (4,))) if coset is not None else None))
+        return a
+
+    def ntt_dev(self, dptr, log_n, inverse=False, coset=None):
+        self._ck(self.lib.plk_ntt_dev(self.h, _vp(dptr), C.c_uint32(log_n), C.c_int32(int(inverse)),
+                                      _ptr(_fr(coset, (4,))) if coset is not None else None))
+
+    def interpolate_selector(self, values):
+        v = _fr(values)
+        n = 1
+        while n < len(v):
+            n *= 2
+        out = np.zeros((n, 4), dtype=np.uint64); log_n = C.c_uint32(0)
+        self._ck(self.lib.plk_interpolate_selector(self.h, _ptr(v), C.c_uint64(len(v)), _ptr(out), C.byref(log_n)))
+        return out
+
+    def interpolate_permutation(self, sigma, log_n4):
+        s = np.ascontiguousarray(sigma, dtype=np.uint64)
+        n4 = 1 << log_n4
+        sid = np.empty((n4, 4), dtype=np.uint64); ssg = np.empty((n4, 4), dtype=np.uint64)
+        self._ck(self.lib.plk_interpolate_permutation(self.h, _ptr(s), C.c_uint64(len(s)), C.c_uint32(log_n4), _ptr(sid), _ptr(ssg)))
+        return sid, ssg
+
+    def interpolate_permutation_dev(self, d_sigma, sigma_len, log_n4, d_sid, d_ssigma):
+        self._ck(self.lib.plk_interpolate_permutation_dev(self.h, _vp(d_sigma), C.c_uint64(sigma_len), C.c_uint32(log_n4), _vp(d_sid), _vp(d_ssigma)))
+
+    # ---- rounds
+    def grand_product(self, witness_flat, sigma, beta, gamma):
+        w = _fr(witness_flat); s = np.ascontiguousarray(sigma, dtype=np.uint64)
+        n = len(w) // 3; log_n = (n - 1).bit_length()
+        out = np.empty((n, 4), dtype=np.uint64)
+        self._ck(self.lib.plk_grand_product(self.h, _ptr(w), _ptr(s), C.c_uint32(log_n), _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))), _ptr(out)))
+        return out
+
+    def grand_product_dev(self, d_w, d_sigma, log_n, beta, gamma, d_out):
+        self._ck(self.lib.plk_grand_product_dev(self.h, _vp(d_w), _vp(d_sigma), C.c_uint32(log_n), _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))), _vp(d_out)))
+
+    def quotient(self, a, b, c, qa, qm, zv, sigma, beta, gamma):
+        a = _fr(a); n = len(a); log_n = (n - 1).bit_length()
+        out = np.empty((n, 4), dtype=np.uint64); tlen = C.c_uint64(0)
+        self._ck(self.lib.plk_quotient(self.h, _ptr(a), _ptr(_fr(b)), _ptr(_fr(c)), _ptr(_fr(qa)), _ptr(_fr(qm)), _ptr(_fr(zv)),
+                                       _ptr(np.ascontiguousarray(sigma, dtype=np.uint64)), C.c_uint32(log_n), _ptr(_fr(beta, (4,))),
+                                       _ptr(_fr(gamma, (4,))), _ptr(out), C.byref(tlen)))
+        return out, tlen.value
+
+    def quotient_dev(self, d_a, d_b, d_c, d_qa, d_qm, d_zv, d_sigma, log_n, beta, gamma, d_t):
+        tlen = C.c_uint64(0)
+        self._ck(self.lib.plk_quotient_dev(self.h, _vp(d_a), _vp(d_b), _vp(d_c), _vp(d_qa), _vp(d_qm), _vp(d_zv), _vp(d_sigma), C.c_uint32(log_n),
+                                           _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))), _vp(d_t), C.byref(tlen)))
+        return tlen.value
+
+    def poly_eval(self, coeffs, x):
+        c = _fr(coeffs); out = np.empty(4, dtype=np.uint64)
+        self._ck(self.lib.plk_poly_eval(self.h, _ptr(c) if len(c) else None, C.c_uint64(len(c)), _ptr(_fr(x, (4,))), _ptr(out)))
+        return out
+
+    # ---- KZG
+    def kzg_commit(self, coeffs, blind):
+        c = _fr(coeffs); out = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)
+        self._ck(self.lib.plk_kzg_commit(self.h, _ptr(c) if len(c) else None, C.c_uint64(len(c)), _ptr(_fr(blind, (12,))), _ptr(out), C.byref(inf)))
+        return out, inf.value
+
+    def kzg_open(self, coeffs, blind, zeta, chal):
+        c = _fr(coeffs); w = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)
+        rv = np.empty(4, dtype=np.uint64); ev = np.empty(4, dtype=np.uint64)
+        self._ck(self.lib.plk_kzg_open(self.h, _ptr(c) if len(c) else None, C.c_uint64(len(c)), _ptr(_fr(blind, (12,))), _ptr(_fr(zeta, (4,))),
+                                       _ptr(_fr(chal, (4,))), _ptr(w), C.byref(inf), _ptr(rv), _ptr(ev)))
+        return w, inf.value, rv, ev
+
+    def commit_begin(self, d_coeffs, length, blind) -> int:
+        t = C.c_int32(-1)
+        self._ck(self.lib.plk_kzg_commit_begin(self.h, _vp(d_coeffs), C.c_uint64(length), _ptr(_fr(blind, (12,))), C.byref(t)))
+        return t.value
+
+    def commit_end(self, ticket):
+        out = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)
+        self._ck(self.lib.plk_kzg_commit_end(self.h, C.c_int32(ticket), _ptr(out), C.byref(inf)))
+        return out, inf.value
+
+    def open_begin(self, d_coeffs, length, blind, zeta, chal) -> int:
+        t = C.c_int32(-1)
+        self._ck(self.lib.plk_kzg_open_begin(self.h, _vp(d_coeffs), C.c_uint64(length), _ptr(_fr(blind, (12,))), _ptr(_fr(zeta, (4,))),
+                                             _ptr(_fr(chal, (4,))), C.byref(t)))
+        return t.value
+
+    def open_end(self, ticket):
+        w = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)
+        rv = np.empty(4, dtype=np.uint64); ev = np.empty(4, dtype=np.uint64)
+        self._ck(self.lib.plk_kzg_open_end(self.h, C.c_int32(ticket), _ptr(w), C.byref(inf), _ptr(rv), _ptr(ev)))
+        return w, inf.value, rv, ev
+
+    def end_partial(self, ticket):
+        out = np.empty(16, dtype=np.uint64); rv = np.zeros(4, dtype=np.uint64); ev = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.plk_kzg_end_partial(self.h, C.c_int32(ticket), _ptr(out), _ptr(rv), _ptr(ev)))
+        return out, rv, ev
+
+    # ---- misc
+    def field_op(self, field, op, a, b):
+        a = _fr(a); b = _fr(b); out = np.empty_like(a)
+        self._ck(self.lib.plk_field_op(self.h, C.c_int32({"fr": 0, "fq": 1}[field]), C.c_int32({"add": 0, "sub": 1, "mul": 2}[op]), _ptr(a), _ptr(b),
+                                       _ptr(out), C.c_uint64(len(a))))
+        return out
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.plk_profile_enable(self.h, C.c_int32(int(on))))
+
+    def profile_reset(self):
+        self._ck(self.lib.plk_profile_reset(self.h))
+
+    def profile_get(self, name):
+        ms = C.c_double(0); n = C.c_uint64(0)
+        self._ck(self.lib.plk_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,162 @@
+"""HIP library vs the CPU oracle, through the C ABI, on seeded inputs (bit-exact: all integer work)."""
+import numpy as np
+import pytest
+
+from oracle import pymodel as pm
+
+pytestmark = pytest.mark.gpu
+
+TAU, GSCAL = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321
+
+
+def rand_fr(orc, n, seed):
+    rng = pm.SplitMix64(seed)
+    return orc.fr_from_ints([rng.next_fr() for _ in range(n)])
+
+
+@pytest.mark.parametrize("field", ["fr", "fq"])
+@pytest.mark.parametrize("op", ["add", "sub", "mul"])
+def test_field_ops(ctx, orc, field, op):
+    rng = pm.SplitMix64(11)
+    p = pm.R_MOD if field == "fr" else pm.Q_MOD
+    xs = [rng.next_fr() for _ in range(500)] + [0, 1, p - 1, p - 1, 0, 2]
+    ys = [rng.next_fr() for _ in range(500)] + [0, p - 1, p - 1, 1, 5, p - 2]
+    conv = orc.fr_from_ints if field == "fr" else orc.fq_from_ints
+    a, b = conv(xs), conv(ys)
+    got = ctx.field_op(field, op, a, b)
+    want = (orc.fr_op if field == "fr" else orc.fq_op)(op, a, b)
+    assert np.array_equal(got, want)
+
+
+@pytest.fixture(scope="module")
+def srs(ctx, orc):
+    n = 1 << 12
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    ctx.srs_generate(tau, gs, n + 1)
+    g = ctx.srs_read(0, 0, n + 1)
+    gg = ctx.srs_read(1, 0, 3)
+    return dict(n=n, g=g, gg=gg, tau=tau, gs=gs)
+
+
+def test_srs_generate_matches_oracle(ctx, orc, srs):
+    one = orc.fr_from_ints([1])[0]
+    want = orc.srs_powers(srs["tau"], one, 0, 64)
+    assert np.array_equal(srs["g"][:64], want)
+    want_hi = orc.srs_powers(srs["tau"], one, srs["n"] - 3, 4)
+    assert np.array_equal(srs["g"][srs["n"] - 3: srs["n"] + 1], want_hi)
+    assert np.array_equal(srs["gg"], orc.srs_powers(srs["tau"], srs["gs"], 0, 3))
+
+
+def test_srs_load_roundtrip(orc):
+    from plonk_amd.hip import Context
+    c2 = Context(0)
+    one = orc.fr_from_ints([1])[0]; tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    g = orc.srs_powers(tau, one, 0, 40); gg = orc.srs_powers(tau, gs, 0, 3)
+    c2.srs_load(g, gg)
+    assert np.array_equal(c2.srs_read(0, 0, 40), g)
+    assert np.array_equal(c2.srs_read(1, 0, 3), gg)
+    sc = rand_fr(orc, 40, 5)
+    got, inf = c2.msm(sc)
+    want, winf = orc.msm(sc, g)
+    assert inf == winf == 0 and np.array_equal(got, want)
+    c2.close()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 17, 64, 1000, 4096, 4097])
+def test_msm_random(ctx, orc, srs, k):
+    sc = rand_fr(orc, k, 100 + k)
+    got, inf = ctx.msm(sc)
+    want, winf = orc.msm(sc, srs["g"][:k])
+    assert inf == winf
+    assert np.array_equal(got, want)
+
+
+def test_msm_edge_scalars(ctx, orc, srs):
+    r = pm.R_MOD
+    vals = [0, 1, 2, r - 1, r - 2, 1 << 15, (1 << 15) + 1, (1 << 16) - 1, 1 << 16, (1 << 253), 3, 7, 14, 19, 57, 0x8000800080008000, 0xFFFFFFFFFFFFFFFF]
+    sc = orc.fr_from_ints(vals)
+    got, inf = ctx.msm(sc, base_offset=5)
+    want, winf = orc.msm(sc, srs["g"][5:5 + len(vals)])
+    assert inf == winf == 0 and np.array_equal(got, want)
+    # all scalars equal (one heavy bucket per window) and cancellation to the identity
+    sc = orc.fr_from_ints([12345] * 300)
+    got, inf = ctx.msm(sc)
+    want, winf = orc.msm(sc, srs["g"][:300])
+    assert inf == winf == 0 and np.array_equal(got, want)
+    zero = orc.fr_from_ints([0] * 10)
+    got, inf = ctx.msm(zero)
+    assert inf == 1
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 10, 11, 12, 13, 16])
+def test_ntt_matches_oracle(ctx, orc, log_n):
+    a = rand_fr(orc, 1 << log_n, 7 + log_n)
+    assert np.array_equal(ctx.ntt(a), orc.ntt(a))
+    assert np.array_equal(ctx.ntt(a, inverse=True), orc.ntt(a, inverse=True))
+    g = orc.fr_from_ints([5])[0]
+    assert np.array_equal(ctx.ntt(a, coset=g), orc.ntt(a, coset=g))
+    assert np.array_equal(ctx.ntt(a, inverse=True, coset=g), orc.ntt(a, inverse=True, coset=g))
+
+
+@pytest.mark.parametrize("length", [0, 1, 2, 31, 32, 33, 1024, 1025, 5000])
+def test_poly_eval(ctx, orc, length):
+    c = rand_fr(orc, length, 3 + length)
+    x = rand_fr(orc, 1, 99)[0]
+    got = ctx.poly_eval(c, x)
+    want = orc.poly_eval(c, x) if length else np.zeros(4, dtype=np.uint64)
+    assert np.array_equal(got, want)
+
+
+def _circuit(orc, log_n, seed):
+    variables, gates = pm.synthetic_circuit(log_n, seed)
+    inp = pm.prepare_inputs(variables, gates)
+    return inp
+
+
+@pytest.mark.parametrize("log_n", [2, 3, 5, 8])
+def test_grand_product_and_quotient(ctx, orc, log_n):
+    inp = _circuit(orc, log_n, 21 + log_n)
+    n = inp["n"]
+    w = orc.fr_from_ints(inp["witness_flat"]); sigma = np.array(inp["sigma"], dtype=np.uint64)
+    beta, gamma = rand_fr(orc, 2, 77)
+    zv, zc = orc.grand_product(w, sigma, beta, gamma)
+    got = ctx.grand_product(w, sigma, beta, gamma)
+    assert np.array_equal(got, zc)
+    a, b, c, qa, qm = (orc.fr_from_ints(col) for col in inp["cols"])
+    t, tlen = ctx.quotient(a, b, c, qa, qm, zv, sigma, beta, gamma)
+    assert tlen == 0 and not t.any()
+    assert orc.quotient(a, b, c, qa, qm, zv, sigma, beta, gamma) == 0
+    # a broken witness must be rejected like the reference's assert
+    from plonk_amd.hip import PlonkHipError
+    bad = c.copy(); bad[1] = a[0]
+    with pytest.raises(PlonkHipError) as e:
+        ctx.quotient(a, b, bad, qa, qm, zv, sigma, beta, gamma)
+    assert e.value.status == "PLK_ERR_NOT_DIVISIBLE"
+    assert orc.quotient(a, b, bad, qa, qm, zv, sigma, beta, gamma) == 1
+
+
+def test_interpolate_permutation(ctx, orc):
+    inp = _circuit(orc, 4, 5)
+    log_n4 = inp["n4"].bit_length() - 1
+    sid, ssg = ctx.interpolate_permutation(np.array(inp["sigma"], dtype=np.uint64), log_n4)
+    assert pm.trim(orc.fr_to_ints(sid)) == inp["s_id"] == [0, 1]
+    assert pm.trim(orc.fr_to_ints(ssg)) == inp["s_sigma"]
+    qa = orc.fr_from_ints(inp["cols"][3])
+    assert pm.trim(orc.fr_to_ints(ctx.interpolate_selector(qa))) == inp["q_add"]
+
+
+@pytest.mark.parametrize("length", [0, 1, 2, 3, 100, 4096])
+def test_kzg_commit_open(ctx, orc, srs, length):
+    coeffs = rand_fr(orc, length, 40 + length)
+    blind = rand_fr(orc, 3, 41 + length)
+    zeta, chal = rand_fr(orc, 2, 42 + length)
+    chal = orc.fr_from_ints([orc.fr_to_ints(chal)[0] & ((1 << 128) - 1)])[0]
+    got, inf = ctx.kzg_commit(coeffs, blind)
+    want, winf = orc.kzg_commit(srs["g"], srs["gg"], coeffs, blind)
+    assert inf == winf and np.array_equal(got, want)
+    w, winf2, rv, ev = ctx.kzg_open(coeffs, blind, zeta, chal)
+    ow, oinf, orv = orc.kzg_open(srs["g"], srs["gg"], coeffs, blind, zeta, chal)
+    assert winf2 == oinf and np.array_equal(w, ow)
+    assert np.array_equal(rv, orv)
+    want_ev = orc.poly_eval(coeffs, zeta) if length else np.zeros(4, dtype=np.uint64)
+    assert np.array_equal(ev, want_ev)
