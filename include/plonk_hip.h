@@ -45,6 +45,8 @@ int32_t plk_free(plk_ctx* ctx, void* dev);
 int32_t plk_upload(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
 int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
 int32_t plk_sync(plk_ctx* ctx);
+/* device-to-device copy of `bytes`, then zero fill up to `total_bytes` (zero padding of DensePolynomial coefficients) */
+int32_t plk_copy_dev(plk_ctx* ctx, void* dev_dst, const void* dev_src, uint64_t bytes, uint64_t total_bytes);
 
 /* ---- structured reference string (KZGProverKey, src/prover.rs:32; built by PCS::trim, src/main.rs:183)
  * powers_of_g[0..len) and powers_of_gamma_g[0..3) as affine x||y.  The library keeps them resident in

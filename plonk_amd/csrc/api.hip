@@ -130,6 +130,13 @@ extern "C" int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_sr
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     return PLK_OK;
 }
+extern "C" int32_t plk_copy_dev(plk_ctx* ctx, void* dev_dst, const void* dev_src, uint64_t bytes, uint64_t total_bytes) {
+    if (!ctx || !dev_dst || (bytes && !dev_src) || total_bytes < bytes) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (bytes) PLK_HIP(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (total_bytes > bytes) PLK_HIP(hipMemsetAsync((char*)dev_dst + bytes, 0, total_bytes - bytes, ctx->stream));
+    return PLK_OK;
+}
 extern "C" int32_t plk_sync(plk_ctx* ctx) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));

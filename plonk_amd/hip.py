@@ -19,7 +19,7 @@ STATUS = {
 }
 # every symbol include/plonk_hip.h declares
 EXPORTS = [
-    "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync",
+    "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync", "plk_copy_dev",
     "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_read",
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",

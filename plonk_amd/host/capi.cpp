@@ -1,0 +1,86 @@
+// C entry points of libplonk_host.so for the Python harness (tests, bench.py, smoke).  They only marshal arguments into
+// the C++ surface of plonk_host.hpp; failures come back as a status code plus the reference-style message.
+#include "plonk_host.hpp"
+#include <string.h>
+#include <string>
+
+using namespace plonk;
+
+namespace {
+thread_local std::string g_err;
+template <class F> int32_t guarded(F&& f) {
+    try { f(); g_err.clear(); return PLK_OK; }
+    catch (const Error& e) { g_err = e.what(); return e.status ? e.status : PLK_ERR_INVALID_ARG; }
+    catch (const std::exception& e) { g_err = e.what(); return PLK_ERR_INVALID_ARG; }
+}
+DensePolynomial poly_of(const uint64_t* p, uint64_t len) {
+    std::vector<Fr> c(len);
+    if (len) memcpy(c.data(), p, len * 32);
+    return DensePolynomial::from_coefficients_vec(std::move(c));
+}
+}  // namespace
+
+extern "C" {
+
+const char* plonk_host_last_error() { return g_err.c_str(); }
+
+int32_t plonk_pk_create(int32_t device, void** out) { return guarded([&] { *out = new KZGProverKey(device); }); }
+int32_t plonk_pk_destroy(void* pk) { return guarded([&] { delete static_cast<KZGProverKey*>(pk); }); }
+void* plonk_pk_ctx(void* pk) { return static_cast<KZGProverKey*>(pk)->ctx(); }
+int32_t plonk_pk_load(void* pk, const uint64_t* g_xy, uint64_t len, const uint64_t* gamma_g_xy) {
+    return guarded([&] { static_cast<KZGProverKey*>(pk)->load(g_xy, len, gamma_g_xy); });
+}
+int32_t plonk_pk_generate(void* pk, const uint64_t* tau, const uint64_t* gscal, uint64_t first, uint64_t count, uint64_t len) {
+    return guarded([&] { Fr t, g; memcpy(t.v, tau, 32); memcpy(g.v, gscal, 32); static_cast<KZGProverKey*>(pk)->generate_shard(t, g, first, count, len); });
+}
+int32_t plonk_pk_set_opening_challenge(void* pk, const uint64_t* c) { return guarded([&] { memcpy(static_cast<KZGProverKey*>(pk)->opening_challenge.v, c, 32); }); }
+// gather(user, mine[16], all[world*16])
+typedef void (*plonk_gather_fn)(void* user, const uint64_t* mine, uint64_t* all);
+int32_t plonk_pk_set_sharding(void* pk, uint32_t rank, uint32_t world, plonk_gather_fn fn, void* user) {
+    return guarded([&] { static_cast<KZGProverKey*>(pk)->set_sharding(rank, world, [fn, user](const uint64_t* m, uint64_t* a) { fn(user, m, a); }); });
+}
+
+// polys: a, b, c, q_add, q_mul, s_id, s_sigma (coefficients, any trailing zeros are stripped as from_coefficients_vec does)
+int32_t plonk_inputs_create(void* pk, const uint64_t* const* polys, const uint64_t* lens, const uint64_t* witness_flat, const uint64_t* sigma, uint32_t log_n,
+                            void** out) {
+    return guarded([&] {
+        const Domain d{log_n};
+        DensePolynomial p[7];
+        for (int i = 0; i < 7; ++i) p[i] = poly_of(polys[i], lens[i]);
+        std::vector<Fr> w(3 * d.size());
+        memcpy(w.data(), witness_flat, w.size() * 32);
+        std::vector<uint64_t> s(sigma, sigma + 3 * d.size());
+        *out = new DeviceInputs(*static_cast<KZGProverKey*>(pk), p[0], p[1], p[2], p[3], p[4], p[5], p[6], w, s, d);
+    });
+}
+int32_t plonk_inputs_destroy(void* in) { return guarded([&] { delete static_cast<DeviceInputs*>(in); }); }
+
+// blinds: the Fr::rand draws in order (27 for a full proof).  proof_bytes: 1170 bytes.  challenges: beta, gamma, alpha, zeta.  seconds[6].
+int32_t plonk_prove(void* pk, void* inputs, const uint64_t* public_inputs, uint64_t n_public, const uint64_t* blinds, uint64_t n_blinds, uint8_t* proof_bytes,
+                    uint64_t* challenges, double* seconds) {
+    return guarded([&] {
+        std::vector<Fr> pub(n_public);
+        if (n_public) memcpy(pub.data(), public_inputs, n_public * 32);
+        uint64_t next = 0;
+        Rng rng = [&]() -> Fr {
+            if (next >= n_blinds) throw Error(PLK_ERR_INVALID_ARG, "rng exhausted: the prover draws 27 field elements");
+            Fr r; memcpy(r.v, blinds + 4 * next, 32); ++next; return r;
+        };
+        ProveTrace tr;
+        const PlonkProof proof = create_plonk_proof_with_transcript(*static_cast<KZGProverKey*>(pk), *static_cast<DeviceInputs*>(inputs), pub, rng, &tr);
+        const std::vector<uint8_t> bytes = serialize_proof(proof);
+        memcpy(proof_bytes, bytes.data(), bytes.size());
+        if (challenges) { memcpy(challenges, tr.beta.v, 32); memcpy(challenges + 4, tr.gamma.v, 32); memcpy(challenges + 8, tr.alpha.v, 32); memcpy(challenges + 12, tr.zeta.v, 32); }
+        if (seconds) memcpy(seconds, tr.seconds, sizeof(tr.seconds));
+    });
+}
+
+void plonk_transcript_kat(uint8_t* out32) {
+    PlonkTranscript t("test protocol");
+    t.append_message("some label", reinterpret_cast<const uint8_t*>("some data"), 9);
+    t.challenge_bytes("challenge", out32, 32);
+}
+void plonk_transcript_empty_beta(uint64_t* out) { PlonkTranscript t("plonk_proof"); const Fr b = t.challenge_beta(); memcpy(out, b.v, 32); }
+void plonk_serialize_g1(const uint64_t* xy, int32_t inf, uint8_t* out32) { G1Affine p; memcpy(p.xy, xy, 64); p.infinity = inf; serialize_g1_compressed(p, out32); }
+
+}  // extern "C"

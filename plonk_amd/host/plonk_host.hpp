@@ -1,0 +1,172 @@
+// Host side of the MI355X prover: the reference's Rust surface restated in C++ above the C ABI of
+// include/plonk_hip.h.  Names, argument meaning and failure behaviour follow the reference:
+//   src/prover.rs      PlonkProof, KZGCommitment, KZGOpeningProof, KZGProverKey, create_plonk_proof_with_transcript
+//   src/circuit.rs     Circuit::build_grand_product, Circuit::build_quotient_polynomial
+//   src/poly_utils.rs  interpolate_selector, interpolate_permutation_polynomials
+//   src/transcript.rs  PlonkTranscript, challenge_scalar, absorb_*
+// The reference panics on failure (unwrap / assert!); here every failure is a plonk::Error exception whose text is the
+// reference's panic message where it has one.  Nothing in this directory touches the CPU oracle.
+#pragma once
+#include <stdint.h>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/plonk_hip.h"
+
+namespace plonk {
+
+struct Error : std::runtime_error {
+    int32_t status;
+    Error(int32_t s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+// ark_bn254::Fr in arkworks' in-memory form: 4 little-endian limbs of x * 2^256 mod r
+struct Fr {
+    uint64_t v[4];
+    bool operator==(const Fr& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2] && v[3] == o.v[3]; }
+    bool is_zero() const { return (v[0] | v[1] | v[2] | v[3]) == 0; }
+};
+struct G1Affine {
+    uint64_t xy[8];      // x || y, each x * 2^256 mod q
+    int32_t infinity;
+};
+// marlin_pc::Commitment { comm, shifted_comm: None }
+struct KZGCommitment {
+    G1Affine comm;
+};
+// kzg10::Proof { w, random_v: Some(_) }
+struct KZGOpeningProof {
+    G1Affine w;
+    Fr random_v;
+};
+// src/prover.rs:61-95, same field order
+struct PlonkProof {
+    Fr eval_a, eval_b, eval_c, eval_q_add, eval_q_mul, eval_s_id, eval_s_sigma, eval_z, eval_t;
+    KZGCommitment comm_a, comm_b, comm_c, comm_q_add, comm_q_mul, comm_s_id, comm_s_sigma, comm_z, comm_t;
+    KZGOpeningProof proof_a, proof_b, proof_c, proof_q_add, proof_q_mul, proof_s_id, proof_s_sigma, proof_z, proof_t;
+};
+// the four Fiat-Shamir challenges and per-round wall-clock seconds, for reports and tests
+struct ProveTrace {
+    Fr beta, gamma, alpha, zeta;
+    double seconds[6];   // round-1 commitments, grand product (+commit), quotient (+commit), openings (+evaluations), assembly, total
+};
+
+// DensePolynomial<Fr>: coefficient vector without trailing zeros
+struct DensePolynomial {
+    std::vector<Fr> coeffs;
+    static DensePolynomial from_coefficients_vec(std::vector<Fr> c) {
+        while (!c.empty() && c.back().is_zero()) c.pop_back();
+        return DensePolynomial{std::move(c)};
+    }
+};
+// GeneralEvaluationDomain<Fr> of size 2^log_size
+struct Domain {
+    uint32_t log_size;
+    uint64_t size() const { return 1ull << log_size; }
+    static Domain with_at_least(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) ++l; return Domain{l}; }
+};
+
+// stands for `rng: &mut R`: every call is one Fr::rand(rng)
+using Rng = std::function<Fr()>;
+
+// Collective used when the SRS is sharded over several GPUs: gathers every rank's 16-limb partial point
+// (X, Y, ZZ, ZZZ) into all[world_size][16].  Single-GPU provers pass nothing.
+using AllGather = std::function<void(const uint64_t* mine, uint64_t* all)>;
+
+// KZGProverKey (src/prover.rs:32): owns a plk_ctx with the powers resident in HBM.
+class KZGProverKey {
+public:
+    explicit KZGProverKey(int32_t device);
+    ~KZGProverKey();
+    KZGProverKey(const KZGProverKey&) = delete;
+    KZGProverKey& operator=(const KZGProverKey&) = delete;
+    // PCS::trim output: powers_of_g[0..len), powers_of_gamma_g[0..3)
+    void load(const uint64_t* g_xy, uint64_t len, const uint64_t* gamma_g_xy);
+    // PCS::setup stand-in with a caller-chosen trapdoor (synthetic SRS)
+    void generate(const Fr& tau, const Fr& gscal, uint64_t len);
+    // this rank keeps powers [first, first + count) of a total of len
+    void generate_shard(const Fr& tau, const Fr& gscal, uint64_t first, uint64_t count, uint64_t len);
+    void set_sharding(uint32_t rank, uint32_t world_size, AllGather gather);
+    plk_ctx* ctx() const { return ctx_; }
+    uint64_t supported_degree() const { return len_ ? len_ - 1 : 0; }
+    // the value PCS::open squeezes from its Poseidon sponge (src/prover.rs:285-303): 128 bits, supplied by the caller
+    Fr opening_challenge{};
+    uint32_t rank = 0, world_size = 1;
+    AllGather gather;
+private:
+    plk_ctx* ctx_ = nullptr;
+    uint64_t len_ = 0;
+};
+
+// The prover's inputs resident in HBM (what create_plonk_proof_with_transcript borrows: seven polynomials,
+// witness_flat, sigma).  Built once, reused for any number of proofs.
+class DeviceInputs {
+public:
+    DeviceInputs(const KZGProverKey& pk, const DensePolynomial& a, const DensePolynomial& b, const DensePolynomial& c, const DensePolynomial& q_add,
+                 const DensePolynomial& q_mul, const DensePolynomial& s_id, const DensePolynomial& s_sigma, const std::vector<Fr>& witness_flat,
+                 const std::vector<uint64_t>& sigma, const Domain& domain);
+    ~DeviceInputs();
+    DeviceInputs(const DeviceInputs&) = delete;
+    Domain domain;
+    uint64_t len[7];
+    void* poly[7];          // a, b, c, q_add, q_mul, s_id, s_sigma
+    void* witness_flat;
+    void* sigma;
+    void* work[5];          // q_add values, q_mul values, z coefficients, z values, t
+private:
+    plk_ctx* ctx_;
+};
+
+// src/prover.rs:119-133
+PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, const DensePolynomial& a, const DensePolynomial& b, const DensePolynomial& c,
+                                              const DensePolynomial& q_add, const DensePolynomial& q_mul, const DensePolynomial& s_id,
+                                              const DensePolynomial& s_sigma, const std::vector<Fr>& public_inputs, const std::vector<Fr>& witness_flat,
+                                              const std::vector<uint64_t>& sigma, const Domain& domain, Rng& rng, ProveTrace* trace = nullptr);
+// the same on inputs that already live in HBM
+PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInputs& in, const std::vector<Fr>& public_inputs, Rng& rng,
+                                              ProveTrace* trace = nullptr);
+
+// src/circuit.rs:491-498 (s_id_vals[j] = j as in src/prover.rs:205)
+DensePolynomial build_grand_product(const KZGProverKey& pk, const std::vector<Fr>& witness_flat, const std::vector<uint64_t>& sigma, const Domain& domain,
+                                    const Fr& beta, const Fr& gamma);
+// src/circuit.rs:442 with the witness table and permutation argument passed explicitly
+DensePolynomial build_quotient_polynomial(const KZGProverKey& pk, const std::vector<Fr>& a_col, const std::vector<Fr>& b_col, const std::vector<Fr>& c_col,
+                                          const std::vector<Fr>& q_add_vals, const std::vector<Fr>& q_mul_vals, const std::vector<Fr>& z_vals,
+                                          const std::vector<uint64_t>& sigma, const Domain& domain, const Fr& beta, const Fr& gamma);
+// src/poly_utils.rs:7 and :14
+DensePolynomial interpolate_selector(const KZGProverKey& pk, const std::vector<Fr>& values);
+std::pair<DensePolynomial, DensePolynomial> interpolate_permutation_polynomials(const KZGProverKey& pk, const std::vector<uint64_t>& sigma, const Domain& domain);
+
+// canonical proof bytes: the fields of PlonkProof in declaration order, each with ark-serialize's compressed encoding
+// (Fr 32 B; Commitment 33 B; Proof 65 B) = 1170 bytes
+std::vector<uint8_t> serialize_proof(const PlonkProof& p);
+void serialize_fr(const Fr& x, uint8_t out[32]);
+void serialize_g1_compressed(const G1Affine& p, uint8_t out[32]);
+
+// src/transcript.rs:55-157 over merlin::Transcript
+class PlonkTranscript {
+public:
+    explicit PlonkTranscript(const char* domain_separator);
+    void append_message(const char* label, const uint8_t* msg, size_t len);
+    void challenge_bytes(const char* label, uint8_t* out, size_t len);
+    void absorb_field(const char* label, const Fr& x);
+    void absorb_commitment(const char* label, const KZGCommitment& c);
+    void absorb_public_inputs(const std::vector<Fr>& public_inputs);
+    void absorb_evaluations(const Fr& a, const Fr& b, const Fr& c, const Fr& q_add, const Fr& q_mul, const Fr& s_id, const Fr& s_sigma, const Fr& z, const Fr& t);
+    Fr challenge_scalar(const char* label);
+    Fr challenge_beta() { return challenge_scalar("beta"); }
+    Fr challenge_gamma() { return challenge_scalar("gamma"); }
+    Fr challenge_alpha() { return challenge_scalar("alpha"); }
+    Fr challenge_zeta() { return challenge_scalar("zeta"); }
+private:
+    void begin_op(uint8_t flags, bool more);
+    void absorb(const uint8_t* d, size_t n);
+    void squeeze(uint8_t* d, size_t n);
+    void run_f();
+    void meta_ad(const uint8_t* d, size_t n, bool more);
+    uint8_t st_[200];
+    uint8_t pos_ = 0, pos_begin_ = 0, cur_flags_ = 0;
+};
+
+}  // namespace plonk

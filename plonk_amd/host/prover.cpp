@@ -1,0 +1,269 @@
+// Round-by-round prover of the reference (src/prover.rs:119-336) above libplonk_hip: the transcript, the rng draws and the
+// serialization run here on the host, every polynomial stays in HBM and only 32..128-byte results cross PCIe.
+#include "plonk_host.hpp"
+#include <string.h>
+#include <chrono>
+#include <deque>
+
+namespace plonk {
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void check(plk_ctx* ctx, int32_t rc) {
+    if (rc == PLK_OK) return;
+    std::string detail = plk_last_error(ctx);
+    switch (rc) {
+        case PLK_ERR_NOT_DIVISIBLE: throw Error(rc, "t(X) not divisible by Z_H(X)");                           // src/circuit.rs:487
+        case PLK_ERR_INVERSE_OF_ZERO: throw Error(rc, "called `Option::unwrap()` on a `None` value: " + detail);  // .inverse().unwrap()
+        case PLK_ERR_INDEX_OUT_OF_RANGE: throw Error(rc, "index out of bounds: " + detail);
+        case PLK_ERR_SRS_TOO_SHORT: throw Error(rc, "called `Result::unwrap()` on an `Err` value: TooManyCoefficients: " + detail);
+        default: throw Error(rc, "libplonk_hip: " + detail);
+    }
+}
+
+struct DevBuf {
+    plk_ctx* ctx;
+    void* p = nullptr;
+    DevBuf(plk_ctx* c, uint64_t bytes) : ctx(c) { check(c, plk_malloc(c, bytes, &p)); }
+    ~DevBuf() { if (p) plk_free(ctx, p); }
+    DevBuf(const DevBuf&) = delete;
+};
+
+const int SLOTS = 4;   // tickets the library keeps open at once
+
+}  // namespace
+
+KZGProverKey::KZGProverKey(int32_t device) {
+    const int32_t rc = plk_create(device, &ctx_);
+    if (rc != PLK_OK) throw Error(rc, "plk_create failed: no usable GPU (there is no CPU fallback)");
+}
+KZGProverKey::~KZGProverKey() { if (ctx_) plk_destroy(ctx_); }
+void KZGProverKey::load(const uint64_t* g_xy, uint64_t len, const uint64_t* gamma_g_xy) {
+    check(ctx_, plk_srs_load(ctx_, g_xy, len, gamma_g_xy));
+    len_ = len;
+}
+void KZGProverKey::generate(const Fr& tau, const Fr& gscal, uint64_t len) {
+    check(ctx_, plk_srs_generate(ctx_, tau.v, gscal.v, len));
+    len_ = len;
+}
+void KZGProverKey::generate_shard(const Fr& tau, const Fr& gscal, uint64_t first, uint64_t count, uint64_t len) {
+    check(ctx_, plk_srs_generate_shard(ctx_, tau.v, gscal.v, first, count, len));
+    len_ = len;
+}
+void KZGProverKey::set_sharding(uint32_t r, uint32_t w, AllGather g) { rank = r; world_size = w; gather = std::move(g); }
+
+DeviceInputs::DeviceInputs(const KZGProverKey& pk, const DensePolynomial& a, const DensePolynomial& b, const DensePolynomial& c, const DensePolynomial& q_add,
+                           const DensePolynomial& q_mul, const DensePolynomial& s_id, const DensePolynomial& s_sigma, const std::vector<Fr>& wflat,
+                           const std::vector<uint64_t>& sg, const Domain& dom)
+    : domain(dom), ctx_(pk.ctx()) {
+    const uint64_t n = dom.size();
+    if (wflat.size() != 3 * n || sg.size() != 3 * n) throw Error(PLK_ERR_INVALID_ARG, "witness_flat and sigma must have 3 * domain.size() entries");
+    const DensePolynomial* polys[7] = {&a, &b, &c, &q_add, &q_mul, &s_id, &s_sigma};
+    for (int i = 0; i < 7; ++i) { poly[i] = nullptr; len[i] = polys[i]->coeffs.size(); }
+    witness_flat = sigma = nullptr;
+    for (auto& w : work) w = nullptr;
+    for (int i = 0; i < 7; ++i) {
+        // selectors are padded to n so that they can be transformed in place copies later
+        const uint64_t cap = (i == 3 || i == 4) ? std::max<uint64_t>(len[i], n) : std::max<uint64_t>(len[i], 1);
+        check(ctx_, plk_malloc(ctx_, cap * 32, &poly[i]));
+        if (len[i]) check(ctx_, plk_upload(ctx_, poly[i], polys[i]->coeffs.data(), len[i] * 32));
+    }
+    check(ctx_, plk_malloc(ctx_, 3 * n * 32, &witness_flat));
+    check(ctx_, plk_upload(ctx_, witness_flat, wflat.data(), 3 * n * 32));
+    check(ctx_, plk_malloc(ctx_, 3 * n * 8, &sigma));
+    check(ctx_, plk_upload(ctx_, sigma, sg.data(), 3 * n * 8));
+    for (auto& w : work) check(ctx_, plk_malloc(ctx_, n * 32, &w));
+}
+DeviceInputs::~DeviceInputs() {
+    for (auto p : poly) if (p) plk_free(ctx_, p);
+    if (witness_flat) plk_free(ctx_, witness_flat);
+    if (sigma) plk_free(ctx_, sigma);
+    for (auto w : work) if (w) plk_free(ctx_, w);
+}
+
+namespace {
+
+// One commitment or opening in flight.
+struct Pending {
+    int32_t ticket;
+    int index;
+};
+
+G1Affine finish_point(const KZGProverKey& pk, int32_t ticket, bool is_open, Fr* random_v, Fr* eval) {
+    plk_ctx* ctx = pk.ctx();
+    G1Affine out;
+    if (pk.world_size <= 1) {
+        if (is_open) check(ctx, plk_kzg_open_end(ctx, ticket, out.xy, &out.infinity, random_v->v, eval->v));
+        else check(ctx, plk_kzg_commit_end(ctx, ticket, out.xy, &out.infinity));
+        return out;
+    }
+    // sharded SRS: this rank holds a partial sum; gather all partials and add them (EC addition is not an RCCL reduction)
+    uint64_t mine[16];
+    Fr rv{}, ev{};
+    check(ctx, plk_kzg_end_partial(ctx, ticket, mine, rv.v, ev.v));
+    std::vector<uint64_t> all((size_t)16 * pk.world_size);
+    pk.gather(mine, all.data());
+    check(ctx, plk_g1_sum_partials(all.data(), pk.world_size, out.xy, &out.infinity));
+    if (is_open) { *random_v = rv; *eval = ev; }
+    return out;
+}
+
+}  // namespace
+
+PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInputs& in, const std::vector<Fr>& public_inputs, Rng& rng, ProveTrace* trace) {
+    plk_ctx* ctx = pk.ctx();
+    const uint64_t n = in.domain.size();
+    const uint32_t log_n = in.domain.log_size;
+    PlonkProof proof;
+    memset(&proof, 0, sizeof(proof));
+    KZGCommitment* comm = &proof.comm_a;       // a, b, c, q_add, q_mul, s_id, s_sigma, z, t
+    KZGOpeningProof* open = &proof.proof_a;
+    Fr* eval = &proof.eval_a;
+    Fr blind[9][3];                             // kzg10::Randomness of each commitment (3 coefficients: hiding bound 1)
+    double t0 = now_s();
+    const double t_start = t0;
+    auto lap = [&](int i) { const double t1 = now_s(); if (trace) trace->seconds[i] = t1 - t0; t0 = t1; };
+
+    PlonkTranscript transcript("plonk_proof");                                  // src/prover.rs:135
+    transcript.absorb_public_inputs(public_inputs);                             // :138
+
+    // ---- round 1: commit a, b, c, q_add, q_mul, s_id, s_sigma in this order (the rng is drawn inside each commit) :150-156
+    {
+        std::deque<Pending> inflight;
+        for (int i = 0; i < 7; ++i) {
+            if ((int)inflight.size() == SLOTS) {
+                const Pending p = inflight.front(); inflight.pop_front();
+                comm[p.index].comm = finish_point(pk, p.ticket, false, nullptr, nullptr);
+            }
+            for (auto& r : blind[i]) r = rng();
+            int32_t ticket;
+            check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket));
+            inflight.push_back({ticket, i});
+        }
+        while (!inflight.empty()) {
+            const Pending p = inflight.front(); inflight.pop_front();
+            comm[p.index].comm = finish_point(pk, p.ticket, false, nullptr, nullptr);
+        }
+    }
+    transcript.absorb_commitment("q_add", proof.comm_q_add);                    // :168-194
+    transcript.absorb_commitment("q_mul", proof.comm_q_mul);
+    transcript.absorb_commitment("a", proof.comm_a);
+    transcript.absorb_commitment("b", proof.comm_b);
+    transcript.absorb_commitment("c", proof.comm_c);
+    transcript.absorb_commitment("s_id", proof.comm_s_id);
+    transcript.absorb_commitment("s_sigma", proof.comm_s_sigma);
+    const Fr beta = transcript.challenge_beta();                                // :197-198
+    const Fr gamma = transcript.challenge_gamma();
+    lap(0);
+
+    // ---- round 2: grand product z, commit :205-216.  The commitment's MSM runs on its own stream while round 3's
+    // transforms and pointwise pass (which need z but not its commitment) use the compute stream.
+    void* z_coeffs = in.work[2];
+    check(ctx, plk_grand_product_dev(ctx, in.witness_flat, in.sigma, log_n, beta.v, gamma.v, z_coeffs));
+    for (auto& r : blind[7]) r = rng();
+    int32_t z_ticket;
+    check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
+    lap(1);
+
+    // ---- round 3: quotient t :224-259
+    uint64_t t_len = 0;
+    int32_t t_ticket = -1;
+    try {
+        if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
+            throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
+        check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
+        check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
+        check(ctx, plk_copy_dev(ctx, in.work[3], z_coeffs, n * 32, n * 32));
+        check(ctx, plk_ntt_dev(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
+        check(ctx, plk_ntt_dev(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
+        check(ctx, plk_ntt_dev(ctx, in.work[3], log_n, 0, nullptr));            // z values     :237
+        check(ctx, plk_quotient_dev(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4],
+                                    &t_len));
+        for (auto& r : blind[8]) r = rng();
+        check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));
+    } catch (...) {
+        finish_point(pk, z_ticket, false, nullptr, nullptr);
+        throw;
+    }
+    comm[7].comm = finish_point(pk, z_ticket, false, nullptr, nullptr);
+    transcript.absorb_commitment("z", proof.comm_z);                           // :214-216
+    const Fr alpha = transcript.challenge_alpha();                              // :219 (enters only the public-input term, which is empty)
+    comm[8].comm = finish_point(pk, t_ticket, false, nullptr, nullptr);
+    transcript.absorb_commitment("t", proof.comm_t);                           // :257-259
+    const Fr zeta = transcript.challenge_zeta();                                // :262
+    lap(2);
+
+    // ---- rounds 4 + 5: evaluations and openings at zeta :266-303.  The division by (X - zeta) yields f(zeta) as its
+    // remainder, so each opening also delivers its evaluation; the transcript absorbs them in the reference's order.
+    {
+        const void* polys[9] = {in.poly[0], in.poly[1], in.poly[2], in.poly[3], in.poly[4], in.poly[5], in.poly[6], z_coeffs, in.work[4]};
+        const uint64_t lens[9] = {in.len[0], in.len[1], in.len[2], in.len[3], in.len[4], in.len[5], in.len[6], n, t_len};
+        std::deque<Pending> inflight;
+        auto finish = [&](const Pending& p) { open[p.index].w = finish_point(pk, p.ticket, true, &open[p.index].random_v, &eval[p.index]); };
+        for (int i = 0; i < 9; ++i) {
+            if ((int)inflight.size() == SLOTS) { finish(inflight.front()); inflight.pop_front(); }
+            int32_t ticket;
+            check(ctx, plk_kzg_open_begin(ctx, polys[i], lens[i], &blind[i][0].v[0], zeta.v, pk.opening_challenge.v, &ticket));
+            inflight.push_back({ticket, i});
+        }
+        while (!inflight.empty()) { finish(inflight.front()); inflight.pop_front(); }
+    }
+    transcript.absorb_evaluations(proof.eval_a, proof.eval_b, proof.eval_c, proof.eval_q_add, proof.eval_q_mul, proof.eval_s_id, proof.eval_s_sigma,
+                                  proof.eval_z, proof.eval_t);                  // :277-282
+    lap(3);
+    if (trace) {
+        trace->beta = beta; trace->gamma = gamma; trace->alpha = alpha; trace->zeta = zeta;
+        trace->seconds[4] = 0;
+        trace->seconds[5] = now_s() - t_start;
+    }
+    return proof;
+}
+
+PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, const DensePolynomial& a, const DensePolynomial& b, const DensePolynomial& c,
+                                              const DensePolynomial& q_add, const DensePolynomial& q_mul, const DensePolynomial& s_id,
+                                              const DensePolynomial& s_sigma, const std::vector<Fr>& public_inputs, const std::vector<Fr>& witness_flat,
+                                              const std::vector<uint64_t>& sigma, const Domain& domain, Rng& rng, ProveTrace* trace) {
+    DeviceInputs in(pk, a, b, c, q_add, q_mul, s_id, s_sigma, witness_flat, sigma, domain);
+    return create_plonk_proof_with_transcript(pk, in, public_inputs, rng, trace);
+}
+
+DensePolynomial build_grand_product(const KZGProverKey& pk, const std::vector<Fr>& witness_flat, const std::vector<uint64_t>& sigma, const Domain& domain,
+                                    const Fr& beta, const Fr& gamma) {
+    const uint64_t n = domain.size();
+    if (witness_flat.size() < 3 * n || sigma.size() < 3 * n) throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: witness_flat / sigma shorter than 3n");
+    std::vector<Fr> z(n);
+    check(pk.ctx(), plk_grand_product(pk.ctx(), &witness_flat[0].v[0], sigma.data(), domain.log_size, beta.v, gamma.v, &z[0].v[0]));
+    return DensePolynomial::from_coefficients_vec(std::move(z));
+}
+DensePolynomial build_quotient_polynomial(const KZGProverKey& pk, const std::vector<Fr>& a_col, const std::vector<Fr>& b_col, const std::vector<Fr>& c_col,
+                                          const std::vector<Fr>& q_add_vals, const std::vector<Fr>& q_mul_vals, const std::vector<Fr>& z_vals,
+                                          const std::vector<uint64_t>& sigma, const Domain& domain, const Fr& beta, const Fr& gamma) {
+    const uint64_t n = domain.size();
+    for (const auto* v : {&a_col, &b_col, &c_col, &q_add_vals, &q_mul_vals, &z_vals})
+        if (v->size() < n) throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: column shorter than the domain");
+    if (sigma.size() < 3 * n) throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: sigma shorter than 3n");
+    std::vector<Fr> t(n);
+    uint64_t t_len = 0;
+    check(pk.ctx(), plk_quotient(pk.ctx(), &a_col[0].v[0], &b_col[0].v[0], &c_col[0].v[0], &q_add_vals[0].v[0], &q_mul_vals[0].v[0], &z_vals[0].v[0], sigma.data(),
+                                 domain.log_size, beta.v, gamma.v, &t[0].v[0], &t_len));
+    t.resize(t_len);
+    return DensePolynomial::from_coefficients_vec(std::move(t));
+}
+DensePolynomial interpolate_selector(const KZGProverKey& pk, const std::vector<Fr>& values) {
+    if (values.empty()) throw Error(PLK_ERR_INVALID_ARG, "called `Option::unwrap()` on a `None` value");
+    const Domain d = Domain::with_at_least(values.size());
+    std::vector<Fr> out(d.size());
+    uint32_t log_n = 0;
+    check(pk.ctx(), plk_interpolate_selector(pk.ctx(), &values[0].v[0], values.size(), &out[0].v[0], &log_n));
+    return DensePolynomial::from_coefficients_vec(std::move(out));
+}
+std::pair<DensePolynomial, DensePolynomial> interpolate_permutation_polynomials(const KZGProverKey& pk, const std::vector<uint64_t>& sigma, const Domain& domain) {
+    if (sigma.size() > domain.size()) throw Error(PLK_ERR_INVALID_ARG, "Sigma length must match domain size");   // src/poly_utils.rs:22
+    std::vector<Fr> s_id(domain.size()), s_sigma(domain.size());
+    check(pk.ctx(), plk_interpolate_permutation(pk.ctx(), sigma.data(), sigma.size(), domain.log_size, &s_id[0].v[0], &s_sigma[0].v[0]));
+    return {DensePolynomial::from_coefficients_vec(std::move(s_id)), DensePolynomial::from_coefficients_vec(std::move(s_sigma))};
+}
+
+}  // namespace plonk

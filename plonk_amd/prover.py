@@ -1,0 +1,150 @@
+"""Python face of the host prover (libplonk_host.so): the reference's prover.rs / poly_utils.rs surface on one MI355X.
+
+    pk = ProverKey(device=0); pk.generate_srs(tau, gscal, length)
+    inputs = pk.prepare(tables)                  # interpolation on the GPU + upload: src/main.rs:84,187-191
+    proof = pk.prove(inputs, blinds, challenge)  # src/prover.rs:119-336, returns ProofResult
+
+There is no CPU path: a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import hip, synth
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libplonk_host.so")
+HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate",
+                "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
+                "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1"]
+GATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+_host = None
+
+
+def load_host_library():
+    global _host
+    if _host is None:
+        hip.load_library()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise FileNotFoundError(f"{HOST_LIB_PATH} is missing: build it with `make -C plonk_amd/host`")
+        _host = C.CDLL(HOST_LIB_PATH)
+        for name in HOST_EXPORTS:
+            getattr(_host, name)
+        _host.plonk_host_last_error.restype = C.c_char_p
+        _host.plonk_pk_ctx.restype = C.c_void_p
+        _host.plonk_pk_ctx.argtypes = [C.c_void_p]
+    return _host
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(shape) if shape else a
+
+
+@dataclass
+class ProofResult:
+    proof_bytes: bytes          # 1170 bytes: 9 evals, 9 commitments, 9 openings (field order of src/prover.rs:61-95)
+    challenges: np.ndarray      # (4, 4): beta, gamma, alpha, zeta
+    seconds: np.ndarray         # per-round host wall clock, last entry = total
+
+
+class DeviceInputs:
+    def __init__(self, pk, handle, log_n, polys):
+        self.pk, self.h, self.log_n, self.polys = pk, handle, log_n, polys
+
+    def close(self):
+        if self.h:
+            load_host_library().plonk_inputs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ProverKey:
+    """KZGProverKey (src/prover.rs:32) with its powers resident in HBM."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_host_library()
+        h = C.c_void_p()
+        self._ck(self.lib.plonk_pk_create(C.c_int32(device), C.byref(h)))
+        self.h = h
+        self._cb = None
+        # the same plk_ctx seen through the raw C ABI
+        self.ctx = hip.Context.__new__(hip.Context)
+        self.ctx.lib = hip.load_library()
+        self.ctx.h = C.c_void_p(self.lib.plonk_pk_ctx(self.h))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise hip.PlonkHipError(rc, (self.lib.plonk_host_last_error() or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.h = None
+            self.lib.plonk_pk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_srs(self, g_xy, gamma_g_xy):
+        g = _u64(g_xy, (-1, 8))
+        self._ck(self.lib.plonk_pk_load(self.h, _ptr(g), C.c_uint64(len(g)), _ptr(_u64(gamma_g_xy, (-1, 8)))))
+
+    def generate_srs(self, tau, gscal, length, shard_first=0, shard_len=None):
+        sl = length if shard_len is None else shard_len
+        self._ck(self.lib.plonk_pk_generate(self.h, _ptr(_u64(tau, (4,))), _ptr(_u64(gscal, (4,))), C.c_uint64(shard_first), C.c_uint64(sl), C.c_uint64(length)))
+
+    def set_opening_challenge(self, chal):
+        self._ck(self.lib.plonk_pk_set_opening_challenge(self.h, _ptr(_u64(chal, (4,)))))
+
+    def set_sharding(self, rank, world_size, gather):
+        """gather(mine: np.ndarray(16,) uint64) -> np.ndarray(world_size, 16): all ranks' partial points."""
+        def cb(_user, mine, out):
+            m = np.ctypeslib.as_array(mine, shape=(16,)).copy()
+            res = np.ascontiguousarray(gather(m), dtype=np.uint64).reshape(world_size * 16)
+            C.memmove(out, res.ctypes.data, world_size * 16 * 8)
+        self._cb = GATHER_FN(cb)
+        self._ck(self.lib.plonk_pk_set_sharding(self.h, C.c_uint32(rank), C.c_uint32(world_size), self._cb, None))
+
+    def prepare(self, tables) -> DeviceInputs:
+        """src/main.rs:79-84,187-191: interpolates q_add, q_mul, s_id, s_sigma on the GPU and uploads everything."""
+        n, log_n = tables["n"], tables["log_n"]
+        log_n4 = (3 * n - 1).bit_length()
+        q_add = synth.trim(self.ctx.interpolate_selector(tables["q_add_vals"]))
+        q_mul = synth.trim(self.ctx.interpolate_selector(tables["q_mul_vals"]))
+        s_id, s_sigma = self.ctx.interpolate_permutation(tables["sigma"], log_n4)
+        polys = [synth.trim(tables["a"]), synth.trim(tables["b"]), synth.trim(tables["c"]), q_add, q_mul, synth.trim(s_id), synth.trim(s_sigma)]
+        return self.upload(polys, tables["witness_flat"], tables["sigma"], log_n)
+
+    def upload(self, polys, witness_flat, sigma, log_n) -> DeviceInputs:
+        ps = [_u64(p, (-1, 4)) for p in polys]
+        ptrs = (C.c_void_p * 7)(*[p.ctypes.data if len(p) else None for p in ps])
+        lens = np.array([len(p) for p in ps], dtype=np.uint64)
+        h = C.c_void_p()
+        self._ck(self.lib.plonk_inputs_create(self.h, ptrs, _ptr(lens), _ptr(_u64(witness_flat)), _ptr(_u64(sigma)), C.c_uint32(log_n), C.byref(h)))
+        return DeviceInputs(self, h, log_n, ps)
+
+    def prove(self, inputs: DeviceInputs, blinds, public_inputs=None) -> ProofResult:
+        bl = _u64(blinds, (-1, 4))
+        pub = _u64(public_inputs, (-1, 4)) if public_inputs is not None and len(public_inputs) else None
+        proof = np.zeros(1170, dtype=np.uint8); ch = np.zeros((4, 4), dtype=np.uint64); sec = np.zeros(6, dtype=np.float64)
+        self._ck(self.lib.plonk_prove(self.h, inputs.h, _ptr(pub), C.c_uint64(0 if pub is None else len(pub)), _ptr(bl), C.c_uint64(len(bl)), _ptr(proof),
+                                      _ptr(ch), _ptr(sec)))
+        return ProofResult(proof.tobytes(), ch, sec)
