@@ -1,0 +1,200 @@
+"""GPU suite, part 3: committed golden vectors through the HIP path, full-size proofs checked through the SRS trapdoor,
+and point-range sharding (two logical shards on one device; two processes exchanging partial sums over gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import pymodel as pm
+from plonk_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+I = lambda h: int(h, 16)
+
+
+def test_golden_vectors_through_the_c_abi(orc):
+    from plonk_amd.hip import Context
+    from plonk_amd.prover import ProverKey
+    m = json.load(open(os.path.join(G, "msm_kzg.json")))
+    g = orc.points_from_ints([(I(p[0]), I(p[1])) for p in m["srs_g"]]); gg = orc.points_from_ints([(I(p[0]), I(p[1])) for p in m["srs_gg"]])
+    ctx = Context(0)
+    ctx.srs_load(g, gg)
+    for case in m["cases"]:
+        sc = orc.fr_from_ints([I(s) for s in case["scalars"]]) if case["scalars"] else np.zeros((0, 4), np.uint64)
+        out, inf = ctx.msm(sc)
+        want = None if case["result"] is None else (I(case["result"][0]), I(case["result"][1]))
+        assert orc.point_to_ints(out, inf) == want
+    k = m["kzg"]
+    coeffs = orc.fr_from_ints([I(c) for c in k["coeffs"]]); blind = orc.fr_from_ints([I(b) for b in k["blind"]])
+    zeta, chal = orc.fr_from_ints([I(k["zeta"]), I(k["chal"])])
+    c, inf = ctx.kzg_commit(coeffs, blind)
+    assert orc.point_to_ints(c, inf) == (I(k["commit"][0]), I(k["commit"][1]))
+    w, winf, rv, ev = ctx.kzg_open(coeffs, blind, zeta, chal)
+    assert orc.point_to_ints(w, winf) == (I(k["open_w"][0]), I(k["open_w"][1]))
+    assert orc.fr_to_ints(rv)[0] == I(k["random_v"]) and orc.fr_to_ints(ev)[0] == I(k["eval"])
+    for case in json.load(open(os.path.join(G, "ntt.json"))):
+        a = orc.fr_from_ints([I(x) for x in case["input"]]); g5 = orc.fr_from_ints([5])[0]
+        assert orc.fr_to_ints(ctx.ntt(a)) == [I(x) for x in case["fwd"]]
+        assert orc.fr_to_ints(ctx.ntt(a, inverse=True)) == [I(x) for x in case["inv"]]
+        assert orc.fr_to_ints(ctx.ntt(a, coset=g5)) == [I(x) for x in case["coset5_fwd"]]
+        assert orc.fr_to_ints(ctx.ntt(a, inverse=True, coset=g5)) == [I(x) for x in case["coset5_inv"]]
+    ctx.close()
+    pk = ProverKey(0)
+    for p in json.load(open(os.path.join(G, "proofs.json"))):
+        tables = synth.circuit_tables([I(x) for x in p["variables"]], [tuple(x) for x in p["gates"]])
+        tau, gs = synth.to_mont([I(p["tau"]), I(p["gscal"])])
+        pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
+        pk.set_opening_challenge(synth.to_mont([I(p["chal"])])[0])
+        inputs = pk.prepare(tables)
+        res = pk.prove(inputs, synth.to_mont([I(b) for b in p["blinds"]]))
+        assert res.proof_bytes.hex() == p["proof_hex"], p["name"]
+        assert synth.from_mont(res.challenges) == [I(p["beta"]), I(p["gamma"]), I(p["alpha"]), I(p["zeta"])]
+        inputs.close()
+    pk.close()
+
+
+def _decompress(b):
+    q = pm.Q_MOD
+    flags = b[31] & 0xC0
+    x = int.from_bytes(b[:31] + bytes([b[31] & 0x3F]), "little")
+    if flags & 0x40:
+        return None
+    y = pow((x * x * x + 3) % q, (q + 1) // 4, q)
+    assert y * y % q == (x * x * x + 3) % q, "x is not on the curve"
+    if (y > q - y) != bool(flags & 0x80):
+        y = q - y
+    return (x, y)
+
+
+def _check_proof_with_trapdoor(orc, proof, zeta, polys, blinds, chal_int, tau_int, gs_int):
+    """Every commitment equals f(tau) G + r(tau) gamma G, every evaluation equals f(zeta) and every opening satisfies
+    (tau - zeta) W = c C - c v G - random_v gamma G.  polys: 9 coefficient arrays (Montgomery limbs) in proof order."""
+    r = pm.R_MOD
+    tau = synth.to_mont([tau_int])[0]
+    zeta_int = synth.from_mont(zeta)[0]
+    bl = synth.from_mont(blinds)
+    for k in range(9):
+        ev = int.from_bytes(proof[32 * k: 32 * k + 32], "little")
+        C = _decompress(proof[288 + 33 * k: 288 + 33 * k + 32]); assert proof[288 + 33 * k + 32] == 0
+        o = 288 + 297 + 65 * k
+        W = _decompress(proof[o: o + 32]); assert proof[o + 32] == 1
+        rv = int.from_bytes(proof[o + 33: o + 65], "little")
+        f_tau = synth.from_mont(orc.poly_eval(polys[k], tau))[0] if len(polys[k]) else 0
+        f_zeta = synth.from_mont(orc.poly_eval(polys[k], zeta))[0] if len(polys[k]) else 0
+        b0, b1, b2 = bl[3 * k: 3 * k + 3]
+        r_tau = (b0 + b1 * tau_int + b2 * tau_int * tau_int) % r
+        r_zeta = (b0 + b1 * zeta_int + b2 * zeta_int * zeta_int) % r
+        assert ev == f_zeta, f"evaluation {k}"
+        assert C == pm.g1_mul((f_tau + r_tau * gs_int) % r, pm.G1_GEN), f"commitment {k}"
+        assert rv == chal_int * r_zeta % r, f"random_v {k}"
+        assert pm.kzg_check_with_trapdoor(C, W, ev, rv, zeta_int, chal_int, tau_int, gs_int), f"opening {k}"
+
+
+@pytest.mark.parametrize("log_n", [16, 20])
+def test_full_size_proof_through_the_trapdoor(orc, log_n):
+    """BASELINE configs[1] and [2]: 2^16 and 2^20 gates on one MI355X.  A proof is uniquely determined by its inputs, so the
+    trapdoor identities below pin every commitment, evaluation and opening exactly without a 2^20-point MSM on the CPU."""
+    from plonk_amd.prover import ProverKey
+    tau_int, gs_int, chal_int = 0x1F2E3D4C5B6A79880123456789ABCDEF1F2E3D4C5B6A7988, 0x0A1B2C3D4E5F60718293A4B5C6D7E8F9, 0x1234567890ABCDEF1122334455667788
+    pk = ProverKey(0)
+    tables = synth.circuit_tables(*synth.synthetic_circuit(log_n, seed=1))
+    n = tables["n"]
+    tau, gs = synth.to_mont([tau_int, gs_int])
+    pk.generate_srs(tau, gs, 4 * n + 1)
+    pk.set_opening_challenge(synth.to_mont([chal_int])[0])
+    blinds = synth.seeded_scalars(27, 8)
+    inputs = pk.prepare(tables)
+    res = pk.prove(inputs, blinds)
+    _, z_coeffs = orc.grand_product(tables["witness_flat"], tables["sigma"], res.challenges[0], res.challenges[1])
+    polys = list(inputs.polys) + [z_coeffs, np.zeros((0, 4), np.uint64)]
+    _check_proof_with_trapdoor(orc, res.proof_bytes, res.challenges[3], polys, blinds, chal_int, tau_int, gs_int)
+    if log_n == 16:   # the CPU oracle still proves 2^16 gates in seconds: compare every byte
+        g = pk.ctx.srs_read(0, 0, 4 * n + 1); gg = pk.ctx.srs_read(1, 0, 3)
+        rc, want, ch, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], log_n, blinds, synth.to_mont([chal_int])[0])
+        assert rc == 0 and res.proof_bytes == want and np.array_equal(ch, res.challenges)
+    inputs.close()
+    pk.close()
+
+
+def test_two_logical_shards_on_one_device(orc):
+    """Point-range sharding without a second GPU: two contexts each hold half of the SRS; partial sums add up to the full MSM."""
+    from plonk_amd.hip import Context
+    n = 5000
+    tau, gs = synth.seeded_scalars(2, 31)
+    full = Context(0); full.srs_generate(tau, gs, n)
+    lo = Context(0); lo.srs_generate(tau, gs, n, shard_first=0, shard_len=2048)
+    hi = Context(0); hi.srs_generate(tau, gs, n, shard_first=2048, shard_len=n - 2048)
+    assert np.array_equal(hi.srs_read(0, 2048, 16), full.srs_read(0, 2048, 16))
+    sc = synth.seeded_scalars(n, 32)
+    for (k, off) in ((n, 0), (3000, 1000), (100, 10), (100, 3000)):
+        want = full.msm(sc[:k], base_offset=off)
+        parts = []
+        for c in (lo, hi):
+            d = c.upload(sc[:k])
+            parts.append(c.msm_partial_dev(d, k, off))
+            c.free(d)
+        got = full.sum_partials(np.stack(parts))
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+    for c in (full, lo, hi):
+        c.close()
+
+
+WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from plonk_amd import synth
+from plonk_amd.prover import ProverKey
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+tables = synth.circuit_tables(*synth.synthetic_circuit(8, seed=4))
+total = 4 * tables["n"] + 1
+per = (total + world - 1) // world
+pk = ProverKey(0)
+tau, gs = synth.seeded_scalars(2, 7)
+pk.generate_srs(tau, gs, total, shard_first=rank * per, shard_len=min(per, total - rank * per))
+def gather(mine):
+    recv = [torch.zeros(16, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(recv, torch.from_numpy(mine.view(np.int64)))
+    return np.stack([r.numpy().view(np.uint64) for r in recv])
+pk.set_sharding(rank, world, gather)
+pk.set_opening_challenge(synth.to_mont([0xABCDEF0123456789])[0])
+inputs = pk.prepare(tables)
+res = pk.prove(inputs, synth.seeded_scalars(27, 8))
+open(sys.argv[2] + "/proof%d.bin" % rank, "wb").write(res.proof_bytes)
+inputs.close(); pk.close()
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sharded_proof_two_processes(orc, tmp_path):
+    """Two ranks (gloo, both on this box's one GPU): each holds half of the SRS, partial sums are all-gathered, and both
+    ranks finish with the proof the unsharded prover and the CPU oracle produce."""
+    from plonk_amd.prover import ProverKey
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=280)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    proofs = [open(tmp_path / ("proof%d.bin" % r), "rb").read() for r in range(2)]
+    assert proofs[0] == proofs[1]
+    tables = synth.circuit_tables(*synth.synthetic_circuit(8, seed=4))
+    pk = ProverKey(0)
+    tau, gs = synth.seeded_scalars(2, 7)
+    pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
+    chal = synth.to_mont([0xABCDEF0123456789])[0]
+    pk.set_opening_challenge(chal)
+    inputs = pk.prepare(tables)
+    single = pk.prove(inputs, synth.seeded_scalars(27, 8)).proof_bytes
+    g = pk.ctx.srs_read(0, 0, 4 * tables["n"] + 1); gg = pk.ctx.srs_read(1, 0, 3)
+    rc, want, _, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], 8, synth.seeded_scalars(27, 8), chal)
+    assert rc == 0 and single == want == proofs[0]
+    inputs.close(); pk.close()
