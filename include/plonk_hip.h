@@ -80,6 +80,8 @@ int32_t plk_g1_sum_partials(const uint64_t* xyzz, uint64_t count, uint64_t out_x
  * inverse != 0 multiplies by n^-1.  coset_gen != NULL: forward evaluates on g*w^i, inverse interpolates from it. */
 int32_t plk_ntt(plk_ctx* ctx, uint64_t* data_host, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen);
 int32_t plk_ntt_dev(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen);
+/* the same without waiting: the transform is ordered before every later call on this context (plk_sync or any call that returns data waits) */
+int32_t plk_ntt_dev_enqueue(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen);
 
 /* ---- interpolation helpers (src/poly_utils.rs:7-11 and :14-31).  sigma has sigma_len <= 2^log_n4 entries and is
  * padded with the identity; outputs are 2^log_n4 coefficients each (the caller strips trailing zeros, as

@@ -1,4 +1,5 @@
 // Context lifecycle, device memory helpers, measurement hooks and the KZG commit / open entry points.
+#include <mutex>
 #include "common.cuh"
 #include "host_math.hpp"
 #include "kernels.h"
@@ -61,12 +62,12 @@ static int32_t grow(plk_ctx* ctx, hipStream_t st, uint32_t** buf, uint64_t* cap,
     return PLK_OK;
 }
 
-// orders the slot's stream after everything already enqueued on the compute stream
-static int32_t slot_after_compute(plk_ctx* ctx, MsmSlot& s) {
+// orders the sort stream (the entry of the MSM pipeline) after everything already enqueued on the compute stream
+static int32_t sort_after_compute(plk_ctx* ctx) {
     hipEvent_t ev;
     PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     PLK_HIP(hipEventRecord(ev, ctx->stream));
-    PLK_HIP(hipStreamWaitEvent(s.stream, ev, 0));
+    PLK_HIP(hipStreamWaitEvent(ctx->st_sort, ev, 0));
     PLK_HIP(hipEventDestroy(ev));
     return PLK_OK;
 }
@@ -75,6 +76,44 @@ static int32_t slot_after_compute(plk_ctx* ctx, MsmSlot& s) {
 
 using namespace plk;
 
+// Every context of one device shares one set of four streams.  A process that opens many contexts would otherwise hold
+// many more HIP streams than the device has hardware queues (four per priority level here), and dependent work of
+// different contexts multiplexed onto one hardware queue was seen to stop making progress.
+namespace {
+struct DeviceStreams {
+    hipStream_t stream = nullptr, st_sort = nullptr, st_acc = nullptr, st_red = nullptr;
+    int users = 0;
+};
+std::mutex g_streams_mutex;
+std::map<int, DeviceStreams> g_streams;
+
+bool streams_acquire(plk_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    DeviceStreams& d = g_streams[ctx->device];
+    if (d.users == 0) {
+        // the sort and reduction stages are short and latency-bound: their streams get the higher priority
+        if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithPriority(&d.st_sort, hipStreamNonBlocking, -1) != hipSuccess ||
+            hipStreamCreateWithFlags(&d.st_acc, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithPriority(&d.st_red, hipStreamNonBlocking, -1) != hipSuccess)
+            return false;
+    }
+    ++d.users;
+    ctx->stream = d.stream; ctx->st_sort = d.st_sort; ctx->st_acc = d.st_acc; ctx->st_red = d.st_red;
+    return true;
+}
+void streams_release(plk_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    auto it = g_streams.find(ctx->device);
+    if (it == g_streams.end() || !ctx->stream) return;
+    if (--it->second.users == 0) {
+        hipStreamDestroy(it->second.stream); hipStreamDestroy(it->second.st_sort);
+        hipStreamDestroy(it->second.st_acc); hipStreamDestroy(it->second.st_red);
+        g_streams.erase(it);
+    }
+}
+}  // namespace
+
 extern "C" int32_t plk_create(int32_t device, plk_ctx** out) {
     if (!out) return PLK_ERR_INVALID_ARG;
     int count = 0;
@@ -82,8 +121,12 @@ extern "C" int32_t plk_create(int32_t device, plk_ctx** out) {
     if (device < 0 || device >= count) return PLK_ERR_INVALID_ARG;
     plk_ctx* ctx = new plk_ctx();
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&ctx->flag_dev, 64) != hipSuccess || hipHostMalloc(&ctx->flag_host, 64, hipHostMallocDefault) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || !streams_acquire(ctx)) {
+        delete ctx;
+        return PLK_ERR_HIP;
+    }
+    if (hipMalloc(&ctx->flag_dev, 64) != hipSuccess || hipHostMalloc(&ctx->flag_host, 64, hipHostMallocDefault) != hipSuccess) {
+        streams_release(ctx);
         delete ctx;
         return PLK_ERR_HIP;
     }
@@ -98,7 +141,7 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     for (auto& s : ctx->slot) slot_destroy(s);
     ntt_release(ctx);
     hipFree(ctx->tables); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
-    hipStreamDestroy(ctx->stream);
+    streams_release(ctx);
     delete ctx;
     return PLK_OK;
 }
@@ -172,9 +215,9 @@ extern "C" int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, ui
     int si;
     PLK_TRY(msm_acquire_slot(ctx, &si));
     MsmSlot& s = ctx->slot[si];
-    PLK_TRY(slot_after_compute(ctx, s));
+    PLK_TRY(sort_after_compute(ctx));
     memcpy(s.blind_host, blind, 96);
-    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 96, hipMemcpyHostToDevice, s.stream));
+    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 96, hipMemcpyHostToDevice, ctx->st_sort));
     PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)coeffs_dev, len, 0, 3));
     s.busy = true; s.kind = 1;
     *ticket = si;
@@ -224,12 +267,12 @@ extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint
     int si;
     PLK_TRY(msm_acquire_slot(ctx, &si));
     MsmSlot& s = ctx->slot[si];
-    PLK_TRY(grow(ctx, s.stream, &s.scal_dev, &s.scal_cap, (len + 1) * 8));
-    PLK_TRY(grow(ctx, s.stream, &s.chain_dev, &s.chain_cap, division_work_words(len)));
-    PLK_TRY(slot_after_compute(ctx, s));
+    PLK_TRY(grow(ctx, ctx->st_sort, &s.scal_dev, &s.scal_cap, (len + 1) * 8));
+    PLK_TRY(grow(ctx, ctx->st_sort, &s.chain_dev, &s.chain_cap, division_work_words(len)));
+    PLK_TRY(sort_after_compute(ctx));
     // witness polynomial of challenge*f: scalars challenge * h_i, i >= 1; h_0 = f(zeta)
-    PLK_TRY(division_enqueue(ctx, s.stream, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev));
-    PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, s.stream));
+    PLK_TRY(division_enqueue(ctx, ctx->st_sort, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev));
+    PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, ctx->st_sort));
     // hiding part on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2, random_v = r'(zeta)
     using namespace host;
     const el z = el_load(zeta), ch = el_load(challenge);
@@ -239,7 +282,7 @@ extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint
     memcpy(s.host_rv, rv.v, 32);
     memcpy(s.blind_host, hw0.v, 32);
     memcpy(s.blind_host + 8, hw1.v, 32);
-    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 64, hipMemcpyHostToDevice, s.stream));
+    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 64, hipMemcpyHostToDevice, ctx->st_sort));
     PLK_TRY(msm_enqueue(ctx, s, s.scal_dev, len >= 2 ? len - 1 : 0, 0, 2));
     s.busy = true; s.kind = 2;
     *ticket = si;

@@ -15,8 +15,8 @@ namespace plk {
 constexpr int MSM_C = 16;
 constexpr int MSM_WINDOWS = 16;
 constexpr int MSM_BUCKETS = 1 << 15;
-constexpr int MSM_MAX_BLOCKS = 128;     // blocks of the counting / scatter kernels (rows of the count matrix)
-constexpr int MSM_SLOTS = 4;            // MSMs in flight
+constexpr int MSM_MAX_BLOCKS = 256;     // blocks of the counting / scatter kernels (rows of the count matrix)
+constexpr int MSM_SLOTS = 10;           // MSMs in flight (a round of the prover enqueues up to nine at once)
 constexpr int MSM_MARGINALS = 56;       // 16 + 16 + 16 + 8 partial sums handed to the host
 constexpr int XYZZ_WORDS = 36;          // unnormalised point in device scratch: 4 coordinates x 9 limbs
 
@@ -41,8 +41,8 @@ struct PendingEvent {
 };
 
 struct MsmSlot {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
+    bool ready = false;
+    hipEvent_t sorted = nullptr, accumulated = nullptr, done = nullptr;   // stage hand-offs between the three MSM streams
     uint32_t* counts = nullptr;        // [MSM_MAX_BLOCKS][MSM_BUCKETS]
     uint32_t* totals = nullptr;        // [MSM_BUCKETS]
     uint32_t* bucket_start = nullptr;  // [MSM_BUCKETS + 1]
@@ -69,6 +69,10 @@ struct MsmSlot {
 struct plk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // NTT / pointwise work
+    // MSMs are software pipelined by stage: every MSM's sort runs on st_sort, its bucket accumulation on st_acc and its
+    // reduction + read-back on st_red, so the accumulation kernels (70 % of a proof) run back to back while the latency-bound
+    // stages of their neighbours fill in beside them.
+    hipStream_t st_sort = nullptr, st_acc = nullptr, st_red = nullptr;
     plk::MsmSlot slot[plk::MSM_SLOTS];
     int next_slot = 0;
     // SRS

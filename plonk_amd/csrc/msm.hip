@@ -18,6 +18,7 @@
 #include "common.cuh"
 #include "host_math.hpp"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace plk {
 
@@ -45,13 +46,15 @@ __device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint3
     return segs.s[1].scalars + 8ull * idx;
 }
 
-__global__ void __launch_bounds__(1024) k_msm_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t hist[MSM_BUCKETS];
-    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += 1024) hist[i] = 0;
+constexpr int SORT_THREADS = 256;   // four waves per block: a block fits beside the accumulation kernel's waves on a busy CU
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ counts) {
+    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
+    extern __shared__ uint32_t hist[];   // MSM_BUCKETS counters; dynamic so that the compiler does not pad the register allocation to the LDS-limited occupancy
+    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) hist[i] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk;
     const uint32_t hi = min(lo + chunk, segs.total);
-    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += 1024) {
+    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
         uint32_t ti;
         const uint32_t* sp = seg_scalar(segs, idx, &ti);
         int32_t d[MSM_WINDOWS];
@@ -62,35 +65,44 @@ __global__ void __launch_bounds__(1024) k_msm_count(MsmSegs segs, uint32_t chunk
     }
     __syncthreads();
     uint32_t* row = counts + (size_t)blockIdx.x * MSM_BUCKETS;
-    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += 1024) row[i] = hist[i];
+    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) row[i] = hist[i];
 }
 
 __global__ void __launch_bounds__(256) k_msm_totals(const uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ totals) {
+    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     uint32_t s = 0;
     for (uint32_t k = 0; k < nblocks; ++k) s += counts[(size_t)k * MSM_BUCKETS + b];
     totals[b] = s;
 }
-// exclusive scan of MSM_BUCKETS totals by one block of 1024 threads (32 per thread)
-__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bucket_start) {
-    __shared__ uint32_t wave_sum[16];
+// exclusive scan of MSM_BUCKETS totals by one block of 256 threads (128 consecutive buckets per thread; a four-wave block
+// can be placed on a CU that is busy with accumulation waves, a sixteen-wave block cannot)
+__global__ void __launch_bounds__(256) k_msm_scan(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bucket_start) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint32_t wave_sum[4];
+    constexpr int PER = MSM_BUCKETS / 256;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    uint32_t v[32], s = 0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) { v[i] = totals[t * 32 + i]; s += v[i]; }
+    const uint4* src = reinterpret_cast<const uint4*>(totals + t * PER);
+    uint32_t s = 0;
+    for (int i = 0; i < PER / 4; ++i) { const uint4 v = src[i]; s += v.x + v.y + v.z + v.w; }
     uint32_t incl = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += x; }
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t k = 0; k < wave; ++k) base += wave_sum[k];
-    uint32_t run = base + incl - s;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) { bucket_start[t * 32 + i] = run; run += v[i]; }
-    if (t == 1023) bucket_start[MSM_BUCKETS] = run;
+    uint32_t run = incl - s;
+    for (uint32_t k = 0; k < wave; ++k) run += wave_sum[k];
+    uint4* dst = reinterpret_cast<uint4*>(bucket_start + t * PER);
+    for (int i = 0; i < PER / 4; ++i) {
+        const uint4 v = src[i];
+        uint4 o;
+        o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run; run += v.w;
+        dst[i] = o;
+    }
+    if (t == 255) bucket_start[MSM_BUCKETS] = run;
 }
 __global__ void __launch_bounds__(256) k_msm_offsets(uint32_t* __restrict__ counts, uint32_t nblocks, const uint32_t* __restrict__ bucket_start) {
+    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     uint32_t run = bucket_start[b];
     for (uint32_t k = 0; k < nblocks; ++k) {
@@ -100,15 +112,16 @@ __global__ void __launch_bounds__(256) k_msm_offsets(uint32_t* __restrict__ coun
         run += c;
     }
 }
-__global__ void __launch_bounds__(1024) k_msm_scatter(MsmSegs segs, uint32_t chunk, const uint32_t* __restrict__ offsets, uint32_t table_stride,
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(MsmSegs segs, uint32_t chunk, const uint32_t* __restrict__ offsets, uint32_t table_stride,
                                                       uint32_t* __restrict__ entries) {
-    __shared__ uint32_t cursor[MSM_BUCKETS];
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ uint32_t cursor[];   // MSM_BUCKETS write cursors (dynamic LDS, see k_msm_count)
     const uint32_t* row = offsets + (size_t)blockIdx.x * MSM_BUCKETS;
-    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += 1024) cursor[i] = row[i];
+    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) cursor[i] = row[i];
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk;
     const uint32_t hi = min(lo + chunk, segs.total);
-    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += 1024) {
+    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
         uint32_t ti;
         const uint32_t* sp = seg_scalar(segs, idx, &ti);
         int32_t d[MSM_WINDOWS];
@@ -124,28 +137,46 @@ __global__ void __launch_bounds__(1024) k_msm_scatter(MsmSegs segs, uint32_t chu
 }
 
 // ------------------------------------------------------------------------------------------ buckets
+constexpr int ACC_THREADS = 64;   // one wavefront per workgroup: waves retire and are replaced independently, no round quantisation
 // 2^log_g lanes per bucket; lane g takes entries g, g + G, ...; lanes of one bucket are adjacent in a wavefront.
-__global__ void __launch_bounds__(256) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ bucket_start,
-                                                        const uint32_t* __restrict__ tables, uint32_t log_g, uint32_t* __restrict__ bucket_sums) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+// The loop is software pipelined: the table point of entry k+1 and the index of entry k+2 are in flight while entry k is added.
+template <int WAVES>
+__global__ void __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tables, uint32_t log_g,
+                 uint32_t* __restrict__ bucket_sums, uint32_t dbg_mask) {
+    const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
     const uint32_t G = 1u << log_g, b = t >> log_g, g = t & (G - 1);
     const uint32_t start = bucket_start[b], end = bucket_start[b + 1];
     xyzz acc = xyzz_inf();
     uint32_t e = start + g;
-    uint32_t enc = e < end ? entries[e] : 0;
-    while (e < end) {
-        const uint32_t* p = tables + (size_t)(enc & 0x7fffffffu) * 16;
+    if (e < end) {
+        uint32_t enc0 = entries[e];
+        uint32_t enc1 = e + G < end ? entries[e + G] : 0;
         uint32_t wx[8], wy[8];
-        load8(p, wx);
-        load8(p + 8, wy);
-        const uint32_t neg = enc >> 31;
-        e += G;
-        if (e < end) enc = entries[e];
-        aff q;
-        q.x = unpack(wx);
-        q.y = unpack(wy);
-        if (neg) q.y = fq_neg_y(q.y);
-        xyzz_madd(acc, q);
+        {
+            const uint32_t* p = tables + (size_t)(enc0 & dbg_mask) * 16;
+            load8(p, wx);
+            load8(p + 8, wy);
+        }
+        while (true) {
+            const bool more = e + G < end;
+            uint32_t nx[8], ny[8], enc2 = 0;
+            if (more) {
+                const uint32_t* p = tables + (size_t)(enc1 & dbg_mask) * 16;
+                load8(p, nx);
+                load8(p + 8, ny);
+                if (e + 2 * G < end) enc2 = entries[e + 2 * G];
+            }
+            aff q;
+            q.x = unpack(wx);
+            q.y = unpack(wy);
+            if (enc0 >> 31) q.y = fq_neg_y(q.y);
+            xyzz_madd(acc, q);
+            if (!more) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { wx[i] = nx[i]; wy[i] = ny[i]; }
+            enc0 = enc1; enc1 = enc2; e += G;
+        }
     }
     for (uint32_t s = G >> 1; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, (int)s));
     if (g == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
@@ -154,6 +185,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint32_t* __restri
 // One block per output: group d of the bucket index (bits [4d, 4d+4), the last group has 3 bits) equal to v.
 constexpr int MARG_THREADS = 512;
 __global__ void __launch_bounds__(MARG_THREADS) k_msm_marginals(const uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     __shared__ uint32_t part[MARG_THREADS / 64][XYZZ_WORDS];
     const uint32_t o = blockIdx.x;
     const uint32_t d = o < 48 ? o >> 4 : 3, v = o < 48 ? (o & 15) : o - 48;
@@ -230,8 +262,11 @@ __global__ void __launch_bounds__(256) k_srs_generate(const uint32_t* __restrict
 
 // ------------------------------------------------------------------------------------------ host side
 static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
-    if (s.stream) return PLK_OK;
-    PLK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (s.ready) return PLK_OK;
+    PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_count), hipFuncAttributeMaxDynamicSharedMemorySize, MSM_BUCKETS * 4));
+    PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, MSM_BUCKETS * 4));
+    PLK_HIP(hipEventCreateWithFlags(&s.sorted, hipEventDisableTiming));
+    PLK_HIP(hipEventCreateWithFlags(&s.accumulated, hipEventDisableTiming));
     PLK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     PLK_HIP(hipMalloc(&s.counts, (size_t)MSM_MAX_BLOCKS * MSM_BUCKETS * 4));
     PLK_HIP(hipMalloc(&s.totals, (size_t)MSM_BUCKETS * 4));
@@ -243,15 +278,29 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     PLK_HIP(hipHostMalloc(&s.blind_host, 64 * 4, hipHostMallocDefault));
     PLK_HIP(hipMalloc(&s.res_dev, 64 * 4));
     PLK_HIP(hipHostMalloc(&s.res_host, 64 * 4, hipHostMallocDefault));
+    s.ready = true;
+    return PLK_OK;
+}
+// Sizes the per-MSM scratch of every slot for the largest job this SRS admits, so that no allocation (an implicit device
+// synchronisation) happens while proofs are running.
+static int32_t slots_reserve(plk_ctx* ctx) {
+    const uint64_t max_scalars = ctx->shard_len + 3;
+    const uint64_t entries = max_scalars * MSM_WINDOWS + 1024;
+    const uint64_t scal_words = (ctx->srs_total + 1) * 8, chain_words = division_work_words(ctx->srs_total);
+    for (auto& s : ctx->slot) {
+        PLK_TRY(slot_init(ctx, s));
+        if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 4)); s.entries_cap = entries; }
+        if (s.scal_cap < scal_words) { if (s.scal_dev) PLK_HIP(hipFree(s.scal_dev)); s.scal_dev = nullptr; s.scal_cap = 0; PLK_HIP(hipMalloc(&s.scal_dev, scal_words * 4)); s.scal_cap = scal_words; }
+        if (s.chain_cap < chain_words) { if (s.chain_dev) PLK_HIP(hipFree(s.chain_dev)); s.chain_dev = nullptr; s.chain_cap = 0; PLK_HIP(hipMalloc(&s.chain_dev, chain_words * 4)); s.chain_cap = chain_words; }
+    }
     return PLK_OK;
 }
 void slot_destroy(MsmSlot& s) {
-    if (!s.stream) return;
-    hipStreamSynchronize(s.stream);
+    if (!s.ready) return;
     hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.marg_dev);
     hipHostFree(s.marg_host); hipFree(s.blind_dev); hipHostFree(s.blind_host); hipFree(s.scal_dev); hipFree(s.chain_dev);
     hipFree(s.res_dev); hipHostFree(s.res_host);
-    hipEventDestroy(s.done); hipStreamDestroy(s.stream);
+    hipEventDestroy(s.sorted); hipEventDestroy(s.accumulated); hipEventDestroy(s.done);
     s = MsmSlot();
 }
 
@@ -294,37 +343,52 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     segs.nseg = 2;
     segs.total = segs.s[0].count + segs.s[1].count;
     const uint64_t max_entries = (uint64_t)segs.total * MSM_WINDOWS;
-    if (max_entries > s.entries_cap) {
-        PLK_HIP(hipStreamSynchronize(s.stream));
+    if (max_entries > s.entries_cap) {   // the slot is idle here: its previous job was waited for before it was handed out again
         if (s.entries) PLK_HIP(hipFree(s.entries));
         s.entries = nullptr; s.entries_cap = 0;
         const uint64_t cap = max_entries + max_entries / 8 + 1024;
         PLK_HIP(hipMalloc(&s.entries, cap * 4));
         s.entries_cap = cap;
     }
-    uint32_t nblocks = (segs.total + 4095) / 4096;
+    uint32_t nblocks = (segs.total + 8191) / 8192;
     if (nblocks < 1) nblocks = 1;
-    if (nblocks > MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
+    static const uint32_t max_blocks = getenv("PLK_SORT_BLOCKS") ? (uint32_t)atoi(getenv("PLK_SORT_BLOCKS")) : MSM_MAX_BLOCKS;
+    if (nblocks > max_blocks) nblocks = max_blocks;
     const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
-    hipStream_t st = s.stream;
+    hipStream_t st = ctx->st_sort;
     prof_begin(ctx, st, "msm_sort");
-    hipLaunchKernelGGL(k_msm_count, dim3(nblocks), dim3(1024), 0, st, segs, chunk, s.counts);
+    hipLaunchKernelGGL(k_msm_count, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts);
     hipLaunchKernelGGL(k_msm_totals, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.totals);
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, s.totals, s.bucket_start);
+    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(256), 0, st, s.totals, s.bucket_start);
     hipLaunchKernelGGL(k_msm_offsets, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.bucket_start);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks), dim3(1024), 0, st, segs, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries);
     prof_end(ctx, st);
+    PLK_HIP(hipEventRecord(s.sorted, st));
+    st = ctx->st_acc;
+    PLK_HIP(hipStreamWaitEvent(st, s.sorted, 0));
     // lanes per bucket: about 64 entries per lane, at least 8 lanes so that the launch fills the chip
     const uint64_t avg = max_entries / MSM_BUCKETS;
     uint32_t log_g = 3;
     while (log_g < 6 && (avg >> log_g) > 64) ++log_g;
     prof_begin(ctx, st, "msm_accumulate");
-    hipLaunchKernelGGL(k_msm_accumulate, dim3((MSM_BUCKETS << log_g) / 256), dim3(256), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums);
+    {
+        static const int variant = getenv("PLK_ACC_WAVES") ? atoi(getenv("PLK_ACC_WAVES")) : 2;
+        static const uint32_t dbg_mask = getenv("PLK_DBG_MASK") ? (uint32_t)strtoul(getenv("PLK_DBG_MASK"), 0, 16) : 0x7fffffffu;
+        if (getenv("PLK_DBG_LOGG")) log_g = atoi(getenv("PLK_DBG_LOGG"));
+        const dim3 grid((MSM_BUCKETS << log_g) / ACC_THREADS);
+        if (variant == 3) hipLaunchKernelGGL(k_msm_accumulate<3>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums, dbg_mask);
+        else if (variant == 4) hipLaunchKernelGGL(k_msm_accumulate<4>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums, dbg_mask);
+        else hipLaunchKernelGGL(k_msm_accumulate<2>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums, dbg_mask);
+    }
     prof_end(ctx, st);
+    PLK_HIP(hipEventRecord(s.accumulated, st));
+    st = ctx->st_red;
+    PLK_HIP(hipStreamWaitEvent(st, s.accumulated, 0));
     prof_begin(ctx, st, "msm_reduce");
     hipLaunchKernelGGL(k_msm_marginals, dim3(MSM_MARGINALS), dim3(MARG_THREADS), 0, st, s.bucket_sums, s.marg_dev);
     prof_end(ctx, st);
     PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
+    PLK_HIP(hipEventRecord(s.done, st));
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }
@@ -348,7 +412,7 @@ void msm_host_tail(const uint32_t* marg, host::pt* out) {
 }
 
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out) {
-    PLK_HIP(hipStreamSynchronize(s.stream));
+    PLK_HIP(hipEventSynchronize(s.done));
     msm_host_tail(s.marg_host, out);
     return PLK_OK;
 }
@@ -373,7 +437,7 @@ static int32_t srs_build_tables(plk_ctx* ctx) {
     }
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    return PLK_OK;
+    return slots_reserve(ctx);
 }
 
 }  // namespace plk
@@ -481,9 +545,12 @@ extern "C" int32_t plk_msm_partial_dev(plk_ctx* ctx, const void* scalars_dev, ui
     PLK_TRY(msm_acquire_slot(ctx, &si));
     MsmSlot& s = ctx->slot[si];
     PLK_HIP(hipStreamSynchronize(ctx->stream));   // scalars may have been produced on the compute stream
+    s.busy = true;
     PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)scalars_dev, k, base_offset, 0));
     host::pt r;
-    PLK_TRY(msm_wait(ctx, s, &r));
+    const int32_t rc = msm_wait(ctx, s, &r);
+    s.busy = false;
+    PLK_TRY(rc);
     prof_collect(ctx);
     host::pt_store(r, out_xyzz);
     return PLK_OK;

@@ -15,6 +15,9 @@
 
 namespace plk {
 
+struct NttScale {
+    uint32_t w[8];
+};
 constexpr int NTT_TILE = 4096;
 constexpr int NTT_THREADS = 1024;
 
@@ -41,7 +44,7 @@ __device__ __forceinline__ fe mul_tw(const fe& x, const uint32_t* __restrict__ W
 
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ W,
                                                            uint32_t log_n, uint32_t log_r, uint32_t log_ns, uint32_t log_t, int inverse, int last,
-                                                           const uint32_t* __restrict__ scale /* x*2^256 words or null */) {
+                                                           int use_scale, NttScale scale /* x*2^256 words */) {
     __shared__ uint32_t lds[NTT_TILE * 9];
     const uint32_t T = 1u << log_t, R = 1u << log_r, ns_mask = (1u << log_ns) - 1;
     const uint32_t stride = 1u << (log_n - log_r), tile = T << log_r, wg = blockIdx.x;
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint32_t* __rest
         }
         __syncthreads();
     }
-    const fe sc = scale ? mul<FrP>(ld_fe(scale), fe_const(FrP::TO_RP)) : fe_const(FrP::ONE);
+    const fe sc = use_scale ? mul<FrP>(unpack(scale.w), fe_const(FrP::TO_RP)) : fe_const(FrP::ONE);
     for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
         uint32_t jj, u;
         if (log_ns == 0) { u = e & (R - 1); jj = e >> log_r; } else { jj = e & (T - 1); u = e >> log_t; }
@@ -189,11 +192,11 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
         ctx->ntt_tmp_cap = n;
     }
     if (coset_gen && !inverse) PLK_TRY(scale_powers(ctx, st, data, n, host::el_load(coset_gen), host::one(host::FR)));
-    uint32_t* ninv_dev = nullptr;
+    NttScale ninv;
+    memset(&ninv, 0, sizeof(ninv));
     if (inverse) {
-        const host::el ninv = host::inv(host::FR, host::from_u64(host::FR, n));
-        PLK_HIP(hipMalloc(&ninv_dev, 32));
-        PLK_HIP(hipMemcpy(ninv_dev, ninv.v, 32, hipMemcpyHostToDevice));
+        const host::el v = host::inv(host::FR, host::from_u64(host::FR, n));
+        memcpy(ninv.w, v.v, 32);
     }
     prof_begin(ctx, st, "ntt");
     const uint32_t* src = data;
@@ -202,12 +205,11 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
         uint32_t* dst = last ? data : ctx->ntt_tmp[p & 1];
         const uint32_t groups = (uint32_t)(n >> (lr[p] + lt[p]));
         hipLaunchKernelGGL(k_ntt_pass, dim3(groups), dim3(NTT_THREADS), 0, st, src, dst, W, log_n, lr[p], lns[p], lt[p], inverse ? 1 : 0, last ? 1 : 0,
-                           (last && inverse) ? ninv_dev : (const uint32_t*)nullptr);
+                           (last && inverse) ? 1 : 0, ninv);
         src = dst;
     }
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
-    if (ninv_dev) { PLK_HIP(hipStreamSynchronize(st)); PLK_HIP(hipFree(ninv_dev)); }
     if (coset_gen && inverse) {
         const host::el gi = host::inv(host::FR, host::el_load(coset_gen));
         PLK_TRY(scale_powers(ctx, st, data, n, gi, host::one(host::FR)));
@@ -219,10 +221,13 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
 
 using namespace plk;
 
-extern "C" int32_t plk_ntt_dev(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen) {
+extern "C" int32_t plk_ntt_dev_enqueue(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen) {
     if (!ctx || !data_dev) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
-    PLK_TRY(ntt_run(ctx, ctx->stream, (uint32_t*)data_dev, log_n, inverse != 0, coset_gen));
+    return ntt_run(ctx, ctx->stream, (uint32_t*)data_dev, log_n, inverse != 0, coset_gen);
+}
+extern "C" int32_t plk_ntt_dev(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen) {
+    PLK_TRY(plk_ntt_dev_enqueue(ctx, data_dev, log_n, inverse, coset_gen));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     return PLK_OK;

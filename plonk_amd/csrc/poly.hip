@@ -40,33 +40,66 @@ __global__ void __launch_bounds__(256) k_field_op(int op, const uint32_t* __rest
 // ------------------------------------------------------------------------------------------ suffix Horner scan
 constexpr int DIV_L = 32;   // elements per thread
 
+// Loads DIV_L/4 groups of four consecutive elements (one 128-byte line each) per lane, so that the per-lane walk over
+// consecutive coefficients still moves whole lines.
+__device__ __forceinline__ void load_quad(const uint32_t* __restrict__ c, uint64_t i0, uint64_t len, fe out[4]) {
+    if (i0 + 4 <= len) {
+        uint4 r[8];
+        const uint4* p = reinterpret_cast<const uint4*>(c + 8 * i0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = p[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t w[8] = {r[2 * k].x, r[2 * k].y, r[2 * k].z, r[2 * k].w, r[2 * k + 1].x, r[2 * k + 1].y, r[2 * k + 1].z, r[2 * k + 1].w};
+            out[k] = unpack(w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = i0 + k < len ? ld_fe(c + 8 * (i0 + k)) : fe_zero();
+    }
+}
+
 // S[t] = sum_{i in chunk t} c_i z^(i - t L)      (stored with bound 2)
 __global__ void __launch_bounds__(256) k_div_local(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, uint32_t* __restrict__ S) {
+    __builtin_amdgcn_s_setprio(3);
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t lo = t * DIV_L;
     if (lo >= len) return;
-    const uint64_t hi = lo + DIV_L < len ? lo + DIV_L : len;
     const fe z = to_rp(fe_of(zeta));
-    fe h = ld_fe(c + 8 * (hi - 1));
-    for (uint64_t i = hi - 1; i-- > lo;) h = add(ld_fe(c + 8 * i), mul<FrP>(h, z));
+    fe h = fe_zero();
+#pragma unroll 1
+    for (int q = DIV_L / 4 - 1; q >= 0; --q) {
+        fe v[4];
+        load_quad(c, lo + 4 * q, len, v);     // elements past the end read as zero: they do not change the sum
+#pragma unroll
+        for (int k = 3; k >= 0; --k) h = add(v[k], mul<FrP>(h, z));
+    }
     st_lazy(S + 8 * t, mul<FrP>(h, fe_const(FrP::ONE)));   // back to bound 2 so that every level starts alike
 }
 // h_i = c_i + z h_{i+1} inside chunk t, entered with carry[t + 1] (the suffix value at the start of the next chunk).
 // hs != null: hs[i] = h_i (lazy).  q_out != null: q_out[i - 1] = scale * h_i for i >= 1.  h0_out != null: h_0, canonical.
 __global__ void __launch_bounds__(256) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry, uint64_t n_carry,
                                                    uint32_t* __restrict__ hs, uint32_t* __restrict__ q_out, W8 scale, uint32_t* __restrict__ h0_out) {
+    __builtin_amdgcn_s_setprio(3);
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t lo = t * DIV_L;
     if (lo >= len) return;
-    const uint64_t hi = lo + DIV_L < len ? lo + DIV_L : len;
     const fe z = to_rp(fe_of(zeta));
     const fe sc = q_out ? to_rp(fe_of(scale)) : fe_zero();
     fe h = (carry && t + 1 < n_carry) ? ld_fe(carry + 8 * (t + 1)) : fe_zero();
-    for (uint64_t i = hi; i-- > lo;) {
-        h = add(ld_fe(c + 8 * i), mul<FrP>(h, z));      // bound 4, limbs < 2^30
-        if (hs) { fe n = h; norm(n); st_lazy(hs + 8 * i, n); }
-        if (q_out && i >= 1) st_fe<FrP>(q_out + 8 * (i - 1), mul<FrP>(h, sc));
-        if (h0_out && i == 0) st_fe<FrP>(h0_out, mul<FrP>(h, fe_const(FrP::ONE)));
+#pragma unroll 1
+    for (int q = DIV_L / 4 - 1; q >= 0; --q) {
+        fe v[4];
+        load_quad(c, lo + 4 * q, len, v);
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const uint64_t i = lo + 4 * q + k;
+            if (i >= len) continue;
+            h = add(v[k], mul<FrP>(h, z));      // bound 4, limbs < 2^30
+            if (hs) { fe n = h; norm(n); st_lazy(hs + 8 * i, n); }
+            if (q_out && i >= 1) st_fe<FrP>(q_out + 8 * (i - 1), mul<FrP>(h, sc));
+            if (h0_out && i == 0) st_fe<FrP>(h0_out, mul<FrP>(h, fe_const(FrP::ONE)));
+        }
     }
 }
 

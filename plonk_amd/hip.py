@@ -21,7 +21,7 @@ STATUS = {
 EXPORTS = [
     "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync", "plk_copy_dev",
     "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_read",
-    "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev",
+    "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
     "plk_grand_product", "plk_grand_product_dev", "plk_quotient", "plk_quotient_dev", "plk_poly_eval", "plk_poly_eval_dev",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",

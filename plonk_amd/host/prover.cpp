@@ -3,7 +3,7 @@
 #include "plonk_host.hpp"
 #include <string.h>
 #include <chrono>
-#include <deque>
+#include <algorithm>
 
 namespace plonk {
 
@@ -31,7 +31,6 @@ struct DevBuf {
     DevBuf(const DevBuf&) = delete;
 };
 
-const int SLOTS = 4;   // tickets the library keeps open at once
 
 }  // namespace
 
@@ -85,12 +84,6 @@ DeviceInputs::~DeviceInputs() {
 
 namespace {
 
-// One commitment or opening in flight.
-struct Pending {
-    int32_t ticket;
-    int index;
-};
-
 G1Affine finish_point(const KZGProverKey& pk, int32_t ticket, bool is_open, Fr* random_v, Fr* eval) {
     plk_ctx* ctx = pk.ctx();
     G1Affine out;
@@ -129,23 +122,21 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
     PlonkTranscript transcript("plonk_proof");                                  // src/prover.rs:135
     transcript.absorb_public_inputs(public_inputs);                             // :138
 
-    // ---- round 1: commit a, b, c, q_add, q_mul, s_id, s_sigma in this order (the rng is drawn inside each commit) :150-156
+    // ---- round 1: commit a, b, c, q_add, q_mul, s_id, s_sigma :150-156.  The rng is drawn in that order (each commit draws its
+    // three blinding coefficients); the seven independent MSMs are then enqueued longest first and collected afterwards.
     {
-        std::deque<Pending> inflight;
-        for (int i = 0; i < 7; ++i) {
-            if ((int)inflight.size() == SLOTS) {
-                const Pending p = inflight.front(); inflight.pop_front();
-                comm[p.index].comm = finish_point(pk, p.ticket, false, nullptr, nullptr);
-            }
+        for (int i = 0; i < 7; ++i)
             for (auto& r : blind[i]) r = rng();
-            int32_t ticket;
-            check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket));
-            inflight.push_back({ticket, i});
+        int order[7] = {0, 1, 2, 3, 4, 5, 6};
+        // three ordinary-sized MSMs lead so that the accumulation stream starts after a short sort and the long sort of the
+        // 4n-sized s_sigma hides behind them; the rest follows longest first
+        std::stable_sort(order + 3, order + 7, [&](int x, int y) { return in.len[x] > in.len[y]; });
+        int32_t ticket[7];
+        for (int k = 0; k < 7; ++k) {
+            const int i = order[k];
+            check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
         }
-        while (!inflight.empty()) {
-            const Pending p = inflight.front(); inflight.pop_front();
-            comm[p.index].comm = finish_point(pk, p.ticket, false, nullptr, nullptr);
-        }
+        for (int i = 0; i < 7; ++i) comm[i].comm = finish_point(pk, ticket[i], false, nullptr, nullptr);
     }
     transcript.absorb_commitment("q_add", proof.comm_q_add);                    // :168-194
     transcript.absorb_commitment("q_mul", proof.comm_q_mul);
@@ -176,9 +167,9 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
         check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
         check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
         check(ctx, plk_copy_dev(ctx, in.work[3], z_coeffs, n * 32, n * 32));
-        check(ctx, plk_ntt_dev(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
-        check(ctx, plk_ntt_dev(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
-        check(ctx, plk_ntt_dev(ctx, in.work[3], log_n, 0, nullptr));            // z values     :237
+        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
+        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
+        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[3], log_n, 0, nullptr));            // z values     :237
         check(ctx, plk_quotient_dev(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4],
                                     &t_len));
         for (auto& r : blind[8]) r = rng();
@@ -200,15 +191,14 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
     {
         const void* polys[9] = {in.poly[0], in.poly[1], in.poly[2], in.poly[3], in.poly[4], in.poly[5], in.poly[6], z_coeffs, in.work[4]};
         const uint64_t lens[9] = {in.len[0], in.len[1], in.len[2], in.len[3], in.len[4], in.len[5], in.len[6], n, t_len};
-        std::deque<Pending> inflight;
-        auto finish = [&](const Pending& p) { open[p.index].w = finish_point(pk, p.ticket, true, &open[p.index].random_v, &eval[p.index]); };
-        for (int i = 0; i < 9; ++i) {
-            if ((int)inflight.size() == SLOTS) { finish(inflight.front()); inflight.pop_front(); }
-            int32_t ticket;
-            check(ctx, plk_kzg_open_begin(ctx, polys[i], lens[i], &blind[i][0].v[0], zeta.v, pk.opening_challenge.v, &ticket));
-            inflight.push_back({ticket, i});
+        int order[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+        std::stable_sort(order + 3, order + 9, [&](int x, int y) { return lens[x] > lens[y]; });
+        int32_t ticket[9];
+        for (int k = 0; k < 9; ++k) {
+            const int i = order[k];
+            check(ctx, plk_kzg_open_begin(ctx, polys[i], lens[i], &blind[i][0].v[0], zeta.v, pk.opening_challenge.v, &ticket[i]));
         }
-        while (!inflight.empty()) { finish(inflight.front()); inflight.pop_front(); }
+        for (int i = 0; i < 9; ++i) open[i].w = finish_point(pk, ticket[i], true, &open[i].random_v, &eval[i]);
     }
     transcript.absorb_evaluations(proof.eval_a, proof.eval_b, proof.eval_c, proof.eval_q_add, proof.eval_q_mul, proof.eval_s_id, proof.eval_s_sigma,
                                   proof.eval_z, proof.eval_t);                  // :277-282

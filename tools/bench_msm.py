@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Standalone MSM / NTT timing on one MI355X (BASELINE configs[4] style stress, sizes selectable).
+
+    python tools/bench_msm.py --log-n 20 --reps 5 [--ntt]
+Prints per-kernel-class device time (HIP events inside the library) and host wall time per call.
+"""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from plonk_amd import synth
+from plonk_amd.hip import Context
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--log-n", type=int, default=20)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--ntt", action="store_true")
+args = ap.parse_args()
+n = 1 << args.log_n
+ctx = Context(0)
+tau, gs = synth.seeded_scalars(2, 7)
+t0 = time.perf_counter(); ctx.srs_generate(tau, gs, n); t_srs = time.perf_counter() - t0
+rng = np.random.default_rng(2)
+raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+raw[:, 3] &= np.uint64((1 << 60) - 1)          # < 2^252 < r: valid Montgomery residues of uniformly distributed values
+d = ctx.upload(raw)
+ctx.msm_dev(d, n)                               # warm-up (allocations)
+ctx.profile_enable(True); ctx.profile_reset()
+t0 = time.perf_counter()
+for _ in range(args.reps):
+    out = ctx.msm_dev(d, n)
+wall = (time.perf_counter() - t0) / args.reps
+res = {"log_n": args.log_n, "srs_setup_s": round(t_srs, 3), "msm_wall_ms": round(wall * 1e3, 3), "gpts_per_s": round(n / wall / 1e9, 4)}
+for name in ("msm_sort", "msm_accumulate", "msm_reduce"):
+    ms, cnt = ctx.profile_get(name)
+    res[name + "_ms"] = round(ms / max(cnt, 1), 4)
+if args.ntt:
+    g5 = synth.to_mont([5])[0]
+    ctx.ntt_dev(d, args.log_n); ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        ctx.ntt_dev(d, args.log_n)
+    w = (time.perf_counter() - t0) / args.reps
+    ms, cnt = ctx.profile_get("ntt")
+    res.update(ntt_wall_ms=round(w * 1e3, 3), ntt_kernel_ms=round(ms / max(cnt, 1), 4), ntt_GBps=round(64 * n / (ms / max(cnt, 1) * 1e-3) / 1e9, 1))
+    t0 = time.perf_counter(); ctx.ntt_dev(d, args.log_n, coset=g5); ctx.ntt_dev(d, args.log_n, inverse=True, coset=g5)
+    res["coset_roundtrip_wall_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+print(json.dumps(res))
