@@ -81,7 +81,7 @@ using namespace plk;
 // different contexts multiplexed onto one hardware queue was seen to stop making progress.
 namespace {
 struct DeviceStreams {
-    hipStream_t stream = nullptr, st_sort = nullptr, st_acc = nullptr, st_red = nullptr;
+    hipStream_t stream = nullptr, st_sort = nullptr, st_acc[2] = {nullptr, nullptr}, st_red = nullptr;
     int users = 0;
 };
 std::mutex g_streams_mutex;
@@ -91,15 +91,27 @@ bool streams_acquire(plk_ctx* ctx) {
     std::lock_guard<std::mutex> lock(g_streams_mutex);
     DeviceStreams& d = g_streams[ctx->device];
     if (d.users == 0) {
-        // the sort and reduction stages are short and latency-bound: their streams get the higher priority
+        // All streams have the same priority on purpose.  A higher-priority queue whose head is a barrier packet waiting
+        // for an event was seen to starve a normal-priority queue on the same hardware pipe; when that queue carries the
+        // work the barrier waits for, the process hangs.
+        // Four streams, because a process gets four hardware queues per priority level here and streams that share one are
+        // serialised: the front stream (NTT, pointwise and scan kernels, MSM sorts), two accumulation streams, one for reductions.
+        const char* layout = getenv("PLK_STREAM_LAYOUT");
+        const bool one_acc = layout && layout[0] == 'a';
         if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithPriority(&d.st_sort, hipStreamNonBlocking, -1) != hipSuccess ||
-            hipStreamCreateWithFlags(&d.st_acc, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithPriority(&d.st_red, hipStreamNonBlocking, -1) != hipSuccess)
+            hipStreamCreateWithFlags(&d.st_acc[0], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&d.st_red, hipStreamNonBlocking) != hipSuccess)
             return false;
+        if (one_acc) {
+            if (hipStreamCreateWithFlags(&d.st_sort, hipStreamNonBlocking) != hipSuccess) return false;
+            d.st_acc[1] = d.st_acc[0];
+        } else {
+            if (hipStreamCreateWithFlags(&d.st_acc[1], hipStreamNonBlocking) != hipSuccess) return false;
+            d.st_sort = d.stream;
+        }
     }
     ++d.users;
-    ctx->stream = d.stream; ctx->st_sort = d.st_sort; ctx->st_acc = d.st_acc; ctx->st_red = d.st_red;
+    ctx->stream = d.stream; ctx->st_sort = d.st_sort; ctx->st_acc[0] = d.st_acc[0]; ctx->st_acc[1] = d.st_acc[1]; ctx->st_red = d.st_red;
     return true;
 }
 void streams_release(plk_ctx* ctx) {
@@ -107,8 +119,10 @@ void streams_release(plk_ctx* ctx) {
     auto it = g_streams.find(ctx->device);
     if (it == g_streams.end() || !ctx->stream) return;
     if (--it->second.users == 0) {
-        hipStreamDestroy(it->second.stream); hipStreamDestroy(it->second.st_sort);
-        hipStreamDestroy(it->second.st_acc); hipStreamDestroy(it->second.st_red);
+        DeviceStreams& d = it->second;
+        hipStreamDestroy(d.stream); hipStreamDestroy(d.st_acc[0]); hipStreamDestroy(d.st_red);
+        if (d.st_sort != d.stream) hipStreamDestroy(d.st_sort);
+        if (d.st_acc[1] != d.st_acc[0]) hipStreamDestroy(d.st_acc[1]);
         g_streams.erase(it);
     }
 }

@@ -49,6 +49,9 @@ struct MsmSlot {
     uint32_t* entries = nullptr;       // sorted (table index | sign << 31)
     uint64_t entries_cap = 0;
     uint32_t* bucket_sums = nullptr;   // [MSM_BUCKETS][XYZZ_WORDS]
+    uint32_t* flushed = nullptr;       // [MSM_BUCKETS][XYZZ_WORDS] part of a bucket summed by the lane whose run crossed its end
+    uint32_t* tails = nullptr;         // [XYZZ_WORDS][tail_cap] what each accumulation lane held at the end of its run
+    uint64_t tail_cap = 0;
     uint32_t* marg_dev = nullptr;      // [MSM_MARGINALS][32]
     uint32_t* marg_host = nullptr;     // pinned
     uint32_t* blind_dev = nullptr;     // 3 Fr (+ room for opening scalars)
@@ -69,10 +72,12 @@ struct MsmSlot {
 struct plk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // NTT / pointwise work
-    // MSMs are software pipelined by stage: every MSM's sort runs on st_sort, its bucket accumulation on st_acc and its
-    // reduction + read-back on st_red, so the accumulation kernels (70 % of a proof) run back to back while the latency-bound
-    // stages of their neighbours fill in beside them.
-    hipStream_t st_sort = nullptr, st_acc = nullptr, st_red = nullptr;
+    // MSMs are software pipelined by stage: every MSM's sort runs on st_sort, its bucket accumulation on one of the two
+    // st_acc streams (alternating, so the next kernel's waves fill the chip while the previous one drains) and its
+    // reduction + read-back on st_red: the accumulation kernels (most of a proof) run back to back while the
+    // latency-bound stages of their neighbours fill in beside them.
+    hipStream_t st_sort = nullptr, st_acc[2] = {nullptr, nullptr}, st_red = nullptr;
+    unsigned acc_turn = 0;
     plk::MsmSlot slot[plk::MSM_SLOTS];
     int next_slot = 0;
     // SRS
@@ -116,6 +121,12 @@ void prof_end(plk_ctx* ctx, hipStream_t s);
 void prof_collect(plk_ctx* ctx);
 
 int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes);
+
+// Issue priority of the short kernels that run beside the accumulation kernel.
+#ifndef PLK_SIDE_PRIO_LEVEL
+#define PLK_SIDE_PRIO_LEVEL 3
+#endif
+#define PLK_SIDE_PRIO() __builtin_amdgcn_s_setprio(PLK_SIDE_PRIO_LEVEL)
 
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ void load8(const uint32_t* p, uint32_t* w) {

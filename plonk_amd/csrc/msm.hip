@@ -48,7 +48,7 @@ __device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint3
 
 constexpr int SORT_THREADS = 256;   // four waves per block: a block fits beside the accumulation kernel's waves on a busy CU
 __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ counts) {
-    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
+    PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     extern __shared__ uint32_t hist[];   // MSM_BUCKETS counters; dynamic so that the compiler does not pad the register allocation to the LDS-limited occupancy
     for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) hist[i] = 0;
     __syncthreads();
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(MsmSegs segs, uint32
 }
 
 __global__ void __launch_bounds__(256) k_msm_totals(const uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ totals) {
-    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
+    PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     uint32_t s = 0;
     for (uint32_t k = 0; k < nblocks; ++k) s += counts[(size_t)k * MSM_BUCKETS + b];
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) k_msm_totals(const uint32_t* __restrict__
 // exclusive scan of MSM_BUCKETS totals by one block of 256 threads (128 consecutive buckets per thread; a four-wave block
 // can be placed on a CU that is busy with accumulation waves, a sixteen-wave block cannot)
 __global__ void __launch_bounds__(256) k_msm_scan(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bucket_start) {
-    __builtin_amdgcn_s_setprio(3);
+    PLK_SIDE_PRIO();
     __shared__ uint32_t wave_sum[4];
     constexpr int PER = MSM_BUCKETS / 256;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) k_msm_scan(const uint32_t* __restrict__ t
     if (t == 255) bucket_start[MSM_BUCKETS] = run;
 }
 __global__ void __launch_bounds__(256) k_msm_offsets(uint32_t* __restrict__ counts, uint32_t nblocks, const uint32_t* __restrict__ bucket_start) {
-    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
+    PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     uint32_t run = bucket_start[b];
     for (uint32_t k = 0; k < nblocks; ++k) {
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_msm_offsets(uint32_t* __restrict__ coun
 }
 __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(MsmSegs segs, uint32_t chunk, const uint32_t* __restrict__ offsets, uint32_t table_stride,
                                                       uint32_t* __restrict__ entries) {
-    __builtin_amdgcn_s_setprio(3);
+    PLK_SIDE_PRIO();
     extern __shared__ uint32_t cursor[];   // MSM_BUCKETS write cursors (dynamic LDS, see k_msm_count)
     const uint32_t* row = offsets + (size_t)blockIdx.x * MSM_BUCKETS;
     for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) cursor[i] = row[i];
@@ -137,55 +137,125 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(MsmSegs segs, uint
 }
 
 // ------------------------------------------------------------------------------------------ buckets
+// The accumulation kernel keeps two waves of up to 176 registers on every SIMD (352 of 512).  Kernels of neighbouring MSMs
+// that must run beside it are held to the remaining 160, otherwise their waves wait for an accumulation wave to retire and
+// then occupy its place.
+#define SIDE_KERNEL_VGPRS __attribute__((amdgpu_waves_per_eu(4, 4)))
 constexpr int ACC_THREADS = 64;   // one wavefront per workgroup: waves retire and are replaced independently, no round quantisation
-// 2^log_g lanes per bucket; lane g takes entries g, g + G, ...; lanes of one bucket are adjacent in a wavefront.
+// Every lane adds one run of `run` consecutive sorted entries, whatever buckets they belong to, so all lanes do the same
+// amount of work.  When a run crosses the end of bucket b the partial sum goes to flushed[b] (a bucket ends only once);
+// the sum a lane holds at the end of its run goes to tails[lane] (structure of arrays, word i of lane l at i * tail_stride + l).
+// k_msm_fold then rebuilds each bucket from its flushed part and the tails of the lanes whose run ended inside it.
 // The loop is software pipelined: the table point of entry k+1 and the index of entry k+2 are in flight while entry k is added.
+// The run length follows from the number of entries the sort actually produced (zero digits produce none, so a polynomial
+// of zeros with three blinding terms has 48 entries whatever its declared length) and the lanes launched for the worst case.
+__device__ __forceinline__ uint32_t acc_run_length(uint32_t n_entries, uint32_t lanes_launched) {
+    const uint32_t run = (n_entries + lanes_launched - 1) / lanes_launched;
+    return run < 1 ? 1 : run;
+}
 template <int WAVES>
 __global__ void __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tables, uint32_t log_g,
-                 uint32_t* __restrict__ bucket_sums, uint32_t dbg_mask) {
-    const uint32_t t = blockIdx.x * ACC_THREADS + threadIdx.x;
-    const uint32_t G = 1u << log_g, b = t >> log_g, g = t & (G - 1);
-    const uint32_t start = bucket_start[b], end = bucket_start[b + 1];
-    xyzz acc = xyzz_inf();
-    uint32_t e = start + g;
-    if (e < end) {
-        uint32_t enc0 = entries[e];
-        uint32_t enc1 = e + G < end ? entries[e + G] : 0;
-        uint32_t wx[8], wy[8];
-        {
-            const uint32_t* p = tables + (size_t)(enc0 & dbg_mask) * 16;
-            load8(p, wx);
-            load8(p + 8, wy);
-        }
-        while (true) {
-            const bool more = e + G < end;
-            uint32_t nx[8], ny[8], enc2 = 0;
-            if (more) {
-                const uint32_t* p = tables + (size_t)(enc1 & dbg_mask) * 16;
-                load8(p, nx);
-                load8(p + 8, ny);
-                if (e + 2 * G < end) enc2 = entries[e + 2 * G];
-            }
-            aff q;
-            q.x = unpack(wx);
-            q.y = unpack(wy);
-            if (enc0 >> 31) q.y = fq_neg_y(q.y);
-            xyzz_madd(acc, q);
-            if (!more) break;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { wx[i] = nx[i]; wy[i] = ny[i]; }
-            enc0 = enc1; enc1 = enc2; e += G;
+k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tables,
+                 uint32_t* __restrict__ tails, uint32_t tail_stride, uint32_t* __restrict__ flushed) {
+    const uint32_t lane = blockIdx.x * ACC_THREADS + threadIdx.x;
+    const uint32_t n_entries = bucket_start[MSM_BUCKETS];
+    const uint32_t run = acc_run_length(n_entries, gridDim.x * ACC_THREADS);
+    uint32_t e = lane * run;
+    if (e >= n_entries) return;
+    const uint32_t e_end = min(e + run, n_entries);
+    // bucket of the first entry: the largest b with bucket_start[b] <= e (empty buckets share their start with the next one)
+    uint32_t b = 0;
+    {
+        uint32_t hi = MSM_BUCKETS;
+        while (hi - b > 1) {
+            const uint32_t mid = (b + hi) >> 1;
+            if (bucket_start[mid] <= e) b = mid; else hi = mid;
         }
     }
-    for (uint32_t s = G >> 1; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, (int)s));
-    if (g == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
+    uint32_t next = bucket_start[b + 1];
+    xyzz acc = xyzz_inf();
+    uint32_t enc0 = entries[e];
+    uint32_t enc1 = e + 1 < e_end ? entries[e + 1] : 0;
+    uint32_t wx[8], wy[8];
+    {
+        const uint32_t* p = tables + (size_t)(enc0 & 0x7fffffffu) * 16;
+        load8(p, wx);
+        load8(p + 8, wy);
+    }
+    while (true) {
+        const bool more = e + 1 < e_end;
+        uint32_t nx[8], ny[8], enc2 = 0;
+        if (more) {
+            const uint32_t* p = tables + (size_t)(enc1 & 0x7fffffffu) * 16;
+            load8(p, nx);
+            load8(p + 8, ny);
+            if (e + 2 < e_end) enc2 = entries[e + 2];
+        }
+        if (e == next) {   // the run leaves bucket b here
+            st_xyzz(flushed + (size_t)b * XYZZ_WORDS, acc);
+            acc = xyzz_inf();
+            do { ++b; next = bucket_start[b + 1]; } while (next <= e);
+        }
+        aff q;
+        q.x = unpack(wx);
+        q.y = unpack(wy);
+        if (enc0 >> 31) q.y = fq_neg_y(q.y);
+        xyzz_madd(acc, q);
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wx[i] = nx[i]; wy[i] = ny[i]; }
+        enc0 = enc1; enc1 = enc2; ++e;
+    }
+    uint32_t* dst = tails + lane;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        dst[(size_t)i * tail_stride] = acc.x.v[i];
+        dst[(size_t)(9 + i) * tail_stride] = acc.y.v[i];
+        dst[(size_t)(18 + i) * tail_stride] = acc.zz.v[i];
+        dst[(size_t)(27 + i) * tail_stride] = acc.zzz.v[i];
+    }
+}
+
+__device__ __forceinline__ xyzz ld_tail(const uint32_t* tails, uint32_t tail_stride, uint32_t lane) {
+    const uint32_t* src = tails + lane;
+    xyzz r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.v[i] = src[(size_t)i * tail_stride];
+        r.y.v[i] = src[(size_t)(9 + i) * tail_stride];
+        r.zz.v[i] = src[(size_t)(18 + i) * tail_stride];
+        r.zzz.v[i] = src[(size_t)(27 + i) * tail_stride];
+    }
+    return r;
+}
+// bucket_sums[b] = flushed[b] (if the bucket ended inside a run) + the tails of all lanes whose run ended inside bucket b.
+// Four lanes per bucket share the tails, a two-level shuffle tree joins them.
+constexpr int FOLD_LANES = 4;
+__global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tails, uint32_t tail_stride,
+                                                  const uint32_t* __restrict__ flushed, uint32_t lanes_launched, uint32_t* __restrict__ bucket_sums) {
+    PLK_SIDE_PRIO();
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b = t / FOLD_LANES, j = t % FOLD_LANES;
+    const uint32_t first = bucket_start[b], last = bucket_start[b + 1], n_entries = bucket_start[MSM_BUCKETS];
+    const uint32_t run = acc_run_length(n_entries, lanes_launched);
+    xyzz acc = xyzz_inf();
+    if (last > first) {
+        // lane l ends its run at entry (l + 1) * run - 1 (the final lane at n_entries - 1): it belongs here when that entry is in [first, last)
+        const uint32_t m_lo = first / run + 1, m_hi = last / run;
+        for (uint32_t m = m_lo + j; m <= m_hi; m += FOLD_LANES) acc = xyzz_add(acc, ld_tail(tails, tail_stride, m - 1));
+        if (j == FOLD_LANES - 1 && last % run != 0) {
+            if (last < n_entries) acc = xyzz_add(acc, ld_xyzz(flushed + (size_t)b * XYZZ_WORDS));
+            else acc = xyzz_add(acc, ld_tail(tails, tail_stride, m_hi));   // the final, shorter run
+        }
+    }
+    for (int s = FOLD_LANES / 2; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
+    if (j == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
 }
 
 // One block per output: group d of the bucket index (bits [4d, 4d+4), the last group has 3 bits) equal to v.
-constexpr int MARG_THREADS = 512;
-__global__ void __launch_bounds__(MARG_THREADS) k_msm_marginals(const uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ out) {
-    __builtin_amdgcn_s_setprio(3);   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
+constexpr int MARG_THREADS = 256;   // four waves, one per SIMD: a block fits beside the accumulation waves of a busy CU
+__global__ void __launch_bounds__(MARG_THREADS) SIDE_KERNEL_VGPRS k_msm_marginals(const uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ out) {
+    PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     __shared__ uint32_t part[MARG_THREADS / 64][XYZZ_WORDS];
     const uint32_t o = blockIdx.x;
     const uint32_t d = o < 48 ? o >> 4 : 3, v = o < 48 ? (o & 15) : o - 48;
@@ -272,6 +342,7 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     PLK_HIP(hipMalloc(&s.totals, (size_t)MSM_BUCKETS * 4));
     PLK_HIP(hipMalloc(&s.bucket_start, (size_t)(MSM_BUCKETS + 1) * 4));
     PLK_HIP(hipMalloc(&s.bucket_sums, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
+    PLK_HIP(hipMalloc(&s.flushed, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
     PLK_HIP(hipMalloc(&s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4));
     PLK_HIP(hipHostMalloc(&s.marg_host, (size_t)MSM_MARGINALS * 32 * 4, hipHostMallocDefault));
     PLK_HIP(hipMalloc(&s.blind_dev, 64 * 4));
@@ -279,6 +350,29 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     PLK_HIP(hipMalloc(&s.res_dev, 64 * 4));
     PLK_HIP(hipHostMalloc(&s.res_host, 64 * 4, hipHostMallocDefault));
     s.ready = true;
+    return PLK_OK;
+}
+// Entries per lane of the accumulation kernel: close to 64, chosen so that the launch is a whole number of chip-wide rounds
+// (256 CUs x 4 SIMDs x 2 waves x 64 lanes), never below 16.
+static uint32_t acc_run(uint64_t max_entries) {
+    static const uint64_t target = getenv("PLK_ACC_RUN") ? (uint64_t)atoi(getenv("PLK_ACC_RUN")) : 64;
+    const uint64_t chip = 256ull * 4 * 2 * 64;
+    uint64_t rounds = (max_entries + chip * target / 2) / (chip * target);
+    if (rounds < 1) rounds = 1;
+    uint64_t run = (max_entries + rounds * chip - 1) / (rounds * chip);
+    return (uint32_t)(run < 16 ? 16 : run);
+}
+static uint64_t acc_lanes(uint64_t max_entries, uint32_t run) {
+    const uint64_t lanes = (max_entries + run - 1) / run;
+    return lanes < 1 ? 1 : lanes;
+}
+static int32_t tails_reserve(plk_ctx* ctx, MsmSlot& s, uint64_t lanes) {
+    lanes = (lanes + 63) & ~63ull;
+    if (lanes <= s.tail_cap) return PLK_OK;
+    if (s.tails) PLK_HIP(hipFree(s.tails));
+    s.tails = nullptr; s.tail_cap = 0;
+    PLK_HIP(hipMalloc(&s.tails, lanes * XYZZ_WORDS * 4));
+    s.tail_cap = lanes;
     return PLK_OK;
 }
 // Sizes the per-MSM scratch of every slot for the largest job this SRS admits, so that no allocation (an implicit device
@@ -290,6 +384,7 @@ static int32_t slots_reserve(plk_ctx* ctx) {
     for (auto& s : ctx->slot) {
         PLK_TRY(slot_init(ctx, s));
         if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 4)); s.entries_cap = entries; }
+        PLK_TRY(tails_reserve(ctx, s, acc_lanes(entries, acc_run(entries))));
         if (s.scal_cap < scal_words) { if (s.scal_dev) PLK_HIP(hipFree(s.scal_dev)); s.scal_dev = nullptr; s.scal_cap = 0; PLK_HIP(hipMalloc(&s.scal_dev, scal_words * 4)); s.scal_cap = scal_words; }
         if (s.chain_cap < chain_words) { if (s.chain_dev) PLK_HIP(hipFree(s.chain_dev)); s.chain_dev = nullptr; s.chain_cap = 0; PLK_HIP(hipMalloc(&s.chain_dev, chain_words * 4)); s.chain_cap = chain_words; }
     }
@@ -297,7 +392,7 @@ static int32_t slots_reserve(plk_ctx* ctx) {
 }
 void slot_destroy(MsmSlot& s) {
     if (!s.ready) return;
-    hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.marg_dev);
+    hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.flushed); hipFree(s.tails); hipFree(s.marg_dev);
     hipHostFree(s.marg_host); hipFree(s.blind_dev); hipHostFree(s.blind_host); hipFree(s.scal_dev); hipFree(s.chain_dev);
     hipFree(s.res_dev); hipHostFree(s.res_host);
     hipEventDestroy(s.sorted); hipEventDestroy(s.accumulated); hipEventDestroy(s.done);
@@ -350,41 +445,42 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         PLK_HIP(hipMalloc(&s.entries, cap * 4));
         s.entries_cap = cap;
     }
+    PLK_TRY(tails_reserve(ctx, s, acc_lanes(max_entries, acc_run(max_entries))));
     uint32_t nblocks = (segs.total + 8191) / 8192;
     if (nblocks < 1) nblocks = 1;
     static const uint32_t max_blocks = getenv("PLK_SORT_BLOCKS") ? (uint32_t)atoi(getenv("PLK_SORT_BLOCKS")) : MSM_MAX_BLOCKS;
     if (nblocks > max_blocks) nblocks = max_blocks;
     const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
     hipStream_t st = ctx->st_sort;
+    static const int dbg_skip_sort = getenv("PLK_DBG_SKIP_SORT") ? atoi(getenv("PLK_DBG_SKIP_SORT")) : 0;
+    static int dbg_calls = 0;
     prof_begin(ctx, st, "msm_sort");
+    if (!(dbg_skip_sort && ++dbg_calls > dbg_skip_sort)) {
     hipLaunchKernelGGL(k_msm_count, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts);
     hipLaunchKernelGGL(k_msm_totals, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.totals);
     hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(256), 0, st, s.totals, s.bucket_start);
     hipLaunchKernelGGL(k_msm_offsets, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.bucket_start);
     hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries);
+    }
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.sorted, st));
-    st = ctx->st_acc;
+    st = ctx->st_acc[ctx->acc_turn++ & 1];
     PLK_HIP(hipStreamWaitEvent(st, s.sorted, 0));
-    // lanes per bucket: about 64 entries per lane, at least 8 lanes so that the launch fills the chip
-    const uint64_t avg = max_entries / MSM_BUCKETS;
-    uint32_t log_g = 3;
-    while (log_g < 6 && (avg >> log_g) > 64) ++log_g;
+    const uint32_t acc_blocks = (uint32_t)((acc_lanes(max_entries, acc_run(max_entries)) + ACC_THREADS - 1) / ACC_THREADS);
     prof_begin(ctx, st, "msm_accumulate");
     {
-        static const int variant = getenv("PLK_ACC_WAVES") ? atoi(getenv("PLK_ACC_WAVES")) : 2;
-        static const uint32_t dbg_mask = getenv("PLK_DBG_MASK") ? (uint32_t)strtoul(getenv("PLK_DBG_MASK"), 0, 16) : 0x7fffffffu;
-        if (getenv("PLK_DBG_LOGG")) log_g = atoi(getenv("PLK_DBG_LOGG"));
-        const dim3 grid((MSM_BUCKETS << log_g) / ACC_THREADS);
-        if (variant == 3) hipLaunchKernelGGL(k_msm_accumulate<3>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums, dbg_mask);
-        else if (variant == 4) hipLaunchKernelGGL(k_msm_accumulate<4>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums, dbg_mask);
-        else hipLaunchKernelGGL(k_msm_accumulate<2>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, log_g, s.bucket_sums, dbg_mask);
+        static const int waves = getenv("PLK_ACC_WAVES") ? atoi(getenv("PLK_ACC_WAVES")) : 2;
+        const dim3 grid(acc_blocks);
+        if (waves == 3) hipLaunchKernelGGL(k_msm_accumulate<3>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
+        else if (waves == 4) hipLaunchKernelGGL(k_msm_accumulate<4>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
+        else hipLaunchKernelGGL(k_msm_accumulate<2>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
     }
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.accumulated, st));
     st = ctx->st_red;
     PLK_HIP(hipStreamWaitEvent(st, s.accumulated, 0));
     prof_begin(ctx, st, "msm_reduce");
+    hipLaunchKernelGGL(k_msm_fold, dim3(MSM_BUCKETS * FOLD_LANES / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
     hipLaunchKernelGGL(k_msm_marginals, dim3(MSM_MARGINALS), dim3(MARG_THREADS), 0, st, s.bucket_sums, s.marg_dev);
     prof_end(ctx, st);
     PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));

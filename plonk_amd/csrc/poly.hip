@@ -61,7 +61,7 @@ __device__ __forceinline__ void load_quad(const uint32_t* __restrict__ c, uint64
 
 // S[t] = sum_{i in chunk t} c_i z^(i - t L)      (stored with bound 2)
 __global__ void __launch_bounds__(256) k_div_local(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, uint32_t* __restrict__ S) {
-    __builtin_amdgcn_s_setprio(3);
+    PLK_SIDE_PRIO();
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t lo = t * DIV_L;
     if (lo >= len) return;
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_div_local(const uint32_t* __restrict__ 
 // hs != null: hs[i] = h_i (lazy).  q_out != null: q_out[i - 1] = scale * h_i for i >= 1.  h0_out != null: h_0, canonical.
 __global__ void __launch_bounds__(256) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry, uint64_t n_carry,
                                                    uint32_t* __restrict__ hs, uint32_t* __restrict__ q_out, W8 scale, uint32_t* __restrict__ h0_out) {
-    __builtin_amdgcn_s_setprio(3);
+    PLK_SIDE_PRIO();
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t lo = t * DIV_L;
     if (lo >= len) return;

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplonk_hip.so")
+LIB_PATH = os.environ.get("PLK_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libplonk_hip.so")   # the override serves kernel experiments (tools/)
 
 STATUS = {
     0: "PLK_OK", 1: "PLK_ERR_INVALID_ARG", 2: "PLK_ERR_HIP", 3: "PLK_ERR_NO_DEVICE", 4: "PLK_ERR_SRS_TOO_SHORT",

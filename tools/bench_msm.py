@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--log-n", type=int, default=20)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ntt", action="store_true")
+ap.add_argument("--batch", type=int, default=0, help="also time this many hiding commitments in flight at once")
 args = ap.parse_args()
 n = 1 << args.log_n
 ctx = Context(0)
@@ -33,6 +34,18 @@ res = {"log_n": args.log_n, "srs_setup_s": round(t_srs, 3), "msm_wall_ms": round
 for name in ("msm_sort", "msm_accumulate", "msm_reduce"):
     ms, cnt = ctx.profile_get(name)
     res[name + "_ms"] = round(ms / max(cnt, 1), 4)
+if args.batch:
+    blind = synth.seeded_scalars(3, 5)
+    def round_of_commits():
+        tickets = [ctx.commit_begin(d, n, blind) for _ in range(args.batch)]
+        return [ctx.commit_end(t) for t in tickets]
+    round_of_commits(); round_of_commits(); round_of_commits(); ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        round_of_commits()
+    w = (time.perf_counter() - t0) / args.reps
+    res.update(batch=args.batch, batch_wall_ms=round(w * 1e3, 3), batch_ms_per_msm=round(w * 1e3 / args.batch, 3),
+               batch_acc_ms=round(ctx.profile_get("msm_accumulate")[0] / max(1, ctx.profile_get("msm_accumulate")[1]), 4))
 if args.ntt:
     g5 = synth.to_mont([5])[0]
     ctx.ntt_dev(d, args.log_n); ctx.profile_reset()
