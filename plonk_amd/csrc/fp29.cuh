@@ -107,6 +107,41 @@ PLK_HD fe mul(const fe& a, const fe& b) {
     return r;
 }
 
+// (a * b + c * d) * 2^-261 mod p with a single Montgomery reduction; result normalized, bound 2.
+// Needs  9 * (limb(a) * limb(b) + limb(c) * limb(d)) + 9 * 2^58 < 2^64  for the column accumulators
+// (for instance limbs a < 2^29, b < 3 * 2^29, c < 2^30, d < 2^29)  and  bound(a) * bound(b) + bound(c) * bound(d) <= 169.
+template <class F>
+PLK_HD fe mul2(const fe& a, const fe& b, const fe& c, const fe& d) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        m[k] = ((uint32_t)acc * F::NINV) & M29;
+        acc += (uint64_t)m[k] * F::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        r.v[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
 // a * a * 2^-261 mod p; cross products are computed once against the doubled operand
 template <class F>
 PLK_HD fe sqr(const fe& a) {

@@ -28,12 +28,8 @@ PLK_HD xyzz xyzz_from_affine(const aff& q) {
     r.x = q.x; r.y = q.y; r.zz = fe_const(FqP::ONE); r.zzz = fe_const(FqP::ONE);
     return r;
 }
-// -y as 2p - y (normalized, bound 2)
-PLK_HD fe fq_neg_y(const fe& y) {
-    fe r = sub2<FqP>(fe_zero(), y);
-    norm(r);
-    return r;
-}
+// -y as 2p - y for a canonical y: bound 2, limbs < 2^31 (not normalized; fine as a multiplication operand)
+PLK_HD fe fq_neg_y(const fe& y) { return sub2<FqP>(fe_zero(), y); }
 
 // 2 * (x, y) for an affine point, y != 0 on this curve (no points of order two)
 PLK_HD xyzz xyzz_dbl_affine(const aff& q) {
@@ -66,12 +62,12 @@ PLK_HD xyzz xyzz_dbl(const xyzz& p) {
 
 // acc += (q.x, q.y)   (8M + 2S on the common path)
 PLK_HD void xyzz_madd(xyzz& a, const aff& q) {
-    if (xyzz_is_inf(a)) { a = xyzz_from_affine(q); return; }
+    if (xyzz_is_inf(a)) { a = xyzz_from_affine(q); norm(a.y); return; }   // q.y may be the unnormalized 2p - y
     fe u2 = mul<FqP>(q.x, a.zz), s2 = mul<FqP>(q.y, a.zzz);
     fe p = sub8<FqP>(u2, a.x); norm(p);           // bound 10
     fe r = sub4<FqP>(s2, a.y); norm(r);           // bound 6
     if (is_zero_mod<FqP>(p)) {
-        if (is_zero_mod<FqP>(r)) { aff qq = q; a = xyzz_dbl_affine(qq); } else a = xyzz_inf();
+        if (is_zero_mod<FqP>(r)) { aff qq = q; norm(qq.y); a = xyzz_dbl_affine(qq); } else a = xyzz_inf();
         return;
     }
     fe pp = sqr<FqP>(p), ppp = mul<FqP>(p, pp), qv = mul<FqP>(a.x, pp), rr = sqr<FqP>(r);
@@ -79,8 +75,9 @@ PLK_HD void xyzz_madd(xyzz& a, const aff& q) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) x3.v[i] = rr.v[i] + FqP::SUB6X3[i] - ppp.v[i] - 2 * qv.v[i];
     norm(x3);                                     // bound 8
-    fe t = sub8<FqP>(qv, x3);                     // bound 10
-    fe y3 = sub2<FqP>(mul<FqP>(r, t), mul<FqP>(a.y, ppp)); norm(y3);   // bound 4
+    fe t = sub8<FqP>(qv, x3);                     // bound 10, limbs < 3 * 2^29
+    fe ny = sub4<FqP>(fe_zero(), a.y);            // 4p - Y: bound 4, limbs < 2^30
+    fe y3 = mul2<FqP>(r, t, ny, ppp);             // r t - Y ppp in one reduction (60 + 8 <= 169): bound 2
     a.zz = mul<FqP>(a.zz, pp); a.zzz = mul<FqP>(a.zzz, ppp);
     a.x = x3; a.y = y3;
 }
@@ -101,8 +98,9 @@ PLK_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) o.x.v[i] = rr.v[i] + FqP::SUB6X3[i] - ppp.v[i] - 2 * qv.v[i];
     norm(o.x);                                    // bound 8
-    fe t = sub8<FqP>(qv, o.x);
-    o.y = sub2<FqP>(mul<FqP>(r, t), mul<FqP>(s1, ppp)); norm(o.y);     // bound 4
+    fe t = sub8<FqP>(qv, o.x);                    // bound 10, limbs < 3 * 2^29
+    fe ns1 = sub2<FqP>(fe_zero(), s1);            // 2p - S1: bound 2, limbs < 2^30
+    o.y = mul2<FqP>(r, t, ns1, ppp);              // r t - S1 ppp in one reduction (40 + 4 <= 169): bound 2
     o.zz = mul<FqP>(mul<FqP>(a.zz, b.zz), pp);
     o.zzz = mul<FqP>(mul<FqP>(a.zzz, b.zzz), ppp);
     return o;

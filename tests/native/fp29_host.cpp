@@ -13,6 +13,7 @@ template <class F> static void op(int what, const uint32_t* a, const uint32_t* b
         case 4: r = inv<F>(x); break;
         case 5: { fe d = sub2<F>(x, y); norm(d); r = fe_zero(); r.v[0] = is_zero_mod<F>(d) ? 1 : 0; break; }
         case 6: { fe d = sub32<F>(x, y); norm(d); r = fe_zero(); r.v[0] = is_zero_mod<F>(d) ? 1 : 0; break; }
+        case 8: { fe t = sub8<F>(x, y); fe n = sub4<F>(fe_zero(), y); r = mul2<F>(x, t, n, y); break; }   // x (x - y) - y y, operands as fat as xyzz_madd makes them
         default: r = x;
     }
     pack(reduce<F>(r), out);

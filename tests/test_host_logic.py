@@ -52,6 +52,7 @@ def test_fp29_arithmetic(fp29, field):
         b = vals[(i * 7 + 3) % len(vals)]
         assert _call(fn, 0, a, b) == a * b * ri % p
         assert _call(fn, 1, a) == a * a * ri % p
+        assert _call(fn, 8, a, b) == (a * (a - b) - b * b) * ri % p     # two products, one reduction, lazily reduced operands
         assert _call(fn, 2, a, b) == (a + b) % p
         assert _call(fn, 3, a, b) == (a - b) % p
         assert _call(fn, 7, a) == a                                   # unpack / pack round trip
