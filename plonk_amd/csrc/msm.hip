@@ -229,8 +229,8 @@ __device__ __forceinline__ xyzz ld_tail(const uint32_t* tails, uint32_t tail_str
     return r;
 }
 // bucket_sums[b] = flushed[b] (if the bucket ended inside a run) + the tails of all lanes whose run ended inside bucket b.
-// Four lanes per bucket share the tails, a two-level shuffle tree joins them.
-constexpr int FOLD_LANES = 4;
+// FOLD_LANES lanes per bucket share the tails, a shuffle tree joins them.
+template <int FOLD_LANES>
 __global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tails, uint32_t tail_stride,
                                                   const uint32_t* __restrict__ flushed, uint32_t lanes_launched, uint32_t* __restrict__ bucket_sums) {
     PLK_SIDE_PRIO();
@@ -480,7 +480,16 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     st = ctx->st_red;
     PLK_HIP(hipStreamWaitEvent(st, s.accumulated, 0));
     prof_begin(ctx, st, "msm_reduce");
-    hipLaunchKernelGGL(k_msm_fold, dim3(MSM_BUCKETS * FOLD_LANES / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
+    {
+        // runs that end inside an average bucket; two lanes per bucket keep the fold cheap, more lanes keep its serial chain short
+        const uint64_t tails_per_bucket = (uint64_t)acc_blocks * ACC_THREADS / MSM_BUCKETS;
+        if (tails_per_bucket <= 12)
+            hipLaunchKernelGGL(k_msm_fold<2>, dim3(MSM_BUCKETS * 2 / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
+        else if (tails_per_bucket <= 48)
+            hipLaunchKernelGGL(k_msm_fold<4>, dim3(MSM_BUCKETS * 4 / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
+        else
+            hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
+    }
     hipLaunchKernelGGL(k_msm_marginals, dim3(MSM_MARGINALS), dim3(MARG_THREADS), 0, st, s.bucket_sums, s.marg_dev);
     prof_end(ctx, st);
     PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
