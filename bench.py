@@ -24,6 +24,10 @@ HBM_PEAK = 8.0e12
 WINDOWS = 16                # 16-bit signed windows over 254-bit scalars
 MODMUL_PER_MADD = 10        # XYZZ mixed addition: 8 M + 2 S
 MADS_PER_MODMUL = 136       # 8x8 + 8x8 + 8 multiply-adds of an 8x32-bit-limb Montgomery product (the algorithmic count)
+# HBM-side bytes of k_msm_accumulate per (point, window) entry, from rocprofv3 PMC passes over this same command
+# (FETCH_SIZE 1.448 GB + WRITE_SIZE 0.045 GB per launch of 18.64 M entries; profiles/r01_bench20_pmc_*.txt).
+# The algorithmic figure is 64 B table point + 4 B sorted entry = 68 B.
+ACC_TRAFFIC_BYTES_PER_ENTRY = 80.1
 
 
 def cpu_baseline(log_gates_sample, log_gates, seed):
@@ -70,7 +74,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-gates", type=int, default=20)
-    ap.add_argument("--cpu-log-gates", type=int, default=14, help="size of the CPU-baseline sample")
+    ap.add_argument("--cpu-log-gates", type=int, default=16, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -135,7 +139,6 @@ def main():
         stage += res.seconds
     sync()
     dt = time.perf_counter() - t0
-    pk.ctx.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -143,22 +146,51 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     prof = {name: pk.ctx.profile_get(name) for name in ("msm_accumulate", "msm_sort", "msm_reduce", "ntt", "pointwise", "division")}
+    acc_busy_ms = pk.ctx.profile_get_busy("msm_accumulate")
     # dominant kernel: k_msm_accumulate.  One launch per MSM; per proof the launches cover 20n + 45 (point, scalar) pairs in total.
     acc_ms, acc_launches = prof["msm_accumulate"]
     pairs_per_proof = (20 * n + 45) / world
     launches_per_proof = max(1, acc_launches // max(1, args.steps))
     avg_launch_ms = acc_ms / max(1, acc_launches)
     pairs_per_launch = pairs_per_proof / launches_per_proof
-    mads_per_launch = pairs_per_launch * WINDOWS * MODMUL_PER_MADD * MADS_PER_MODMUL
+    mads_per_pair = WINDOWS * MODMUL_PER_MADD * MADS_PER_MODMUL
+    mads_per_launch = pairs_per_launch * mads_per_pair
     achieved = mads_per_launch / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
+    # Consecutive launches alternate between two streams and overlap, so a launch's own duration includes the time it shares the
+    # chip with its neighbour.  "busy" is the time at least one launch was running; the isolated figure below times launches
+    # of one 2^k-coefficient commitment with nothing else on the device (outside the timed region, not part of `value`).
+    achieved_busy = pairs_per_proof * args.steps * mads_per_pair / (acc_busy_ms * 1e-3) if acc_busy_ms > 0 else 0.0
+    pk.ctx.profile_reset()
+    iso_reps = 3
+    iso_poly = np.ascontiguousarray(inputs.polys[0])
+    d_iso = pk.ctx.upload(iso_poly)
+    for _ in range(iso_reps):
+        ticket = pk.ctx.commit_begin(d_iso, len(iso_poly), blinds[:3])
+        if world > 1:
+            pk.ctx.end_partial(ticket)
+        else:
+            pk.ctx.commit_end(ticket)
+    pk.ctx.free(d_iso)
+    iso_ms, iso_n = pk.ctx.profile_get("msm_accumulate")
+    iso_launch_ms = iso_ms / max(1, iso_n)
+    iso_pairs = max(0, min(first + count, len(iso_poly)) - first) + (3 if rank == 0 else 0)
+    achieved_iso = iso_pairs * mads_per_pair / (iso_launch_ms * 1e-3) if iso_launch_ms > 0 else 0.0
+    pk.ctx.profile_enable(False)
     bytes_per_launch = pairs_per_launch * 96.0
+    traffic_per_launch = pairs_per_launch * WINDOWS * ACC_TRAFFIC_BYTES_PER_ENTRY
     roofline = {
         "kernel": "k_msm_accumulate", "bound": "valu_int", "achieved": round(achieved / 1e12, 3), "peak": MAD_PEAK / 1e12,
         "unit": "T mad/s (algorithmic 32-bit multiply-adds: pairs x 16 windows x 10 modmul x 136)", "frac": round(achieved / MAD_PEAK, 4),
-        "traffic": None, "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_proof": int(launches_per_proof),
+        "traffic": round(traffic_per_launch), "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_bench20_pmc_*.txt)",
+        "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_proof": int(launches_per_proof),
         "pairs_per_launch_avg": int(pairs_per_launch),
+        "overlap": {"note": "launches alternate between two streams and overlap; busy = time with at least one launch running",
+                    "busy_ms_per_proof": round(acc_busy_ms / args.steps, 3), "achieved": round(achieved_busy / 1e12, 3), "frac": round(achieved_busy / MAD_PEAK, 4)},
+        "isolated": {"note": "one commitment of 2^%d coefficients at a time, outside the timed region" % log_n, "avg_launch_ms": round(iso_launch_ms, 4),
+                     "pairs": int(iso_pairs), "achieved": round(achieved_iso / 1e12, 3), "frac": round(achieved_iso / MAD_PEAK, 4)},
         "hbm": {"bound": "hbm", "achieved": round(bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else 0.0, "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": round(bytes_per_launch / (avg_launch_ms * 1e-3) / HBM_PEAK, 4) if avg_launch_ms > 0 else 0.0, "bytes_per_pair": 96},
+                "unit": "GB/s", "frac": round(bytes_per_launch / (avg_launch_ms * 1e-3) / HBM_PEAK, 4) if avg_launch_ms > 0 else 0.0, "bytes_per_pair": 96,
+                "traffic_GBps": round(traffic_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else 0.0},
     }
     out = {
         "metric": "prove time @2^%d gates" % log_n, "value": round(ms_per_step, 3), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -145,6 +145,9 @@ int32_t plk_field_op(plk_ctx* ctx, int32_t field, int32_t op, const uint64_t* a_
 int32_t plk_profile_enable(plk_ctx* ctx, int32_t on);
 int32_t plk_profile_reset(plk_ctx* ctx);
 int32_t plk_profile_get(plk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+/* Time during which at least one kernel of the class was running (launches of one class overlap when they sit on
+ * different streams, so this can be less than the sum of their durations). */
+int32_t plk_profile_get_busy(plk_ctx* ctx, const char* name, double* busy_ms);
 
 #ifdef __cplusplus
 }

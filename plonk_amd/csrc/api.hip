@@ -1,4 +1,5 @@
 // Context lifecycle, device memory helpers, measurement hooks and the KZG commit / open entry points.
+#include <algorithm>
 #include <mutex>
 #include "common.cuh"
 #include "host_math.hpp"
@@ -28,18 +29,26 @@ void prof_end(plk_ctx* ctx, hipStream_t s) {
     if (!ctx->profiling || ctx->pending.empty()) return;
     hipEventRecord(ctx->pending.back().e1, s);
 }
-void prof_collect(plk_ctx* ctx) {
-    for (auto& p : ctx->pending) {
-        float ms = 0;
-        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+// Books the brackets whose closing event has completed; with wait = true it blocks for all of them.  Start and end are also
+// kept relative to the event recorded at the last reset, so that the time during which at least one bracket of a name was
+// open (kernels of one name overlap when they run on different streams) can be told from the sum of the durations.
+void prof_collect(plk_ctx* ctx, bool wait) {
+    size_t kept = 0;
+    for (size_t i = 0; i < ctx->pending.size(); ++i) {
+        PendingEvent& p = ctx->pending[i];
+        const hipError_t st = wait ? hipEventSynchronize(p.e1) : hipEventQuery(p.e1);
+        if (st == hipErrorNotReady) { ctx->pending[kept++] = p; continue; }
+        float ms = 0, t0 = 0;
+        if (st == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
             ProfEntry& e = ctx->prof[p.name];
             e.ms += ms;
             e.launches += 1;
+            if (ctx->prof_base && hipEventElapsedTime(&t0, ctx->prof_base, p.e0) == hipSuccess) e.spans.push_back({(double)t0, (double)t0 + ms});
         }
         hipEventDestroy(p.e0);
         hipEventDestroy(p.e1);
     }
-    ctx->pending.clear();
+    ctx->pending.resize(kept);
 }
 
 int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes) {
@@ -96,19 +105,12 @@ bool streams_acquire(plk_ctx* ctx) {
         // work the barrier waits for, the process hangs.
         // Four streams, because a process gets four hardware queues per priority level here and streams that share one are
         // serialised: the front stream (NTT, pointwise and scan kernels, MSM sorts), two accumulation streams, one for reductions.
-        const char* layout = getenv("PLK_STREAM_LAYOUT");
-        const bool one_acc = layout && layout[0] == 'a';
         if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&d.st_acc[0], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&d.st_acc[1], hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&d.st_red, hipStreamNonBlocking) != hipSuccess)
             return false;
-        if (one_acc) {
-            if (hipStreamCreateWithFlags(&d.st_sort, hipStreamNonBlocking) != hipSuccess) return false;
-            d.st_acc[1] = d.st_acc[0];
-        } else {
-            if (hipStreamCreateWithFlags(&d.st_acc[1], hipStreamNonBlocking) != hipSuccess) return false;
-            d.st_sort = d.stream;
-        }
+        d.st_sort = d.stream;
     }
     ++d.users;
     ctx->stream = d.stream; ctx->st_sort = d.st_sort; ctx->st_acc[0] = d.st_acc[0]; ctx->st_acc[1] = d.st_acc[1]; ctx->st_red = d.st_red;
@@ -151,7 +153,8 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    prof_collect(ctx);
+    prof_collect(ctx, true);
+    if (ctx->prof_base) hipEventDestroy(ctx->prof_base);
     for (auto& s : ctx->slot) slot_destroy(s);
     ntt_release(ctx);
     hipFree(ctx->tables); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
@@ -198,7 +201,7 @@ extern "C" int32_t plk_sync(plk_ctx* ctx) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_HIP(hipDeviceSynchronize());
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     return PLK_OK;
 }
 
@@ -209,16 +212,36 @@ extern "C" int32_t plk_profile_enable(plk_ctx* ctx, int32_t on) {
 }
 extern "C" int32_t plk_profile_reset(plk_ctx* ctx) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
-    prof_collect(ctx);
+    PLK_HIP(hipSetDevice(ctx->device));
+    prof_collect(ctx, true);
     ctx->prof.clear();
+    if (!ctx->prof_base) PLK_HIP(hipEventCreate(&ctx->prof_base));
+    PLK_HIP(hipEventRecord(ctx->prof_base, ctx->stream));
+    PLK_HIP(hipEventSynchronize(ctx->prof_base));
     return PLK_OK;
 }
 extern "C" int32_t plk_profile_get(plk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches) {
     if (!ctx || !name || !total_ms || !launches) return PLK_ERR_INVALID_ARG;
-    prof_collect(ctx);
+    prof_collect(ctx, true);
     auto it = ctx->prof.find(name);
     *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
     *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return PLK_OK;
+}
+extern "C" int32_t plk_profile_get_busy(plk_ctx* ctx, const char* name, double* busy_ms) {
+    if (!ctx || !name || !busy_ms) return PLK_ERR_INVALID_ARG;
+    prof_collect(ctx, true);
+    *busy_ms = 0.0;
+    auto it = ctx->prof.find(name);
+    if (it == ctx->prof.end()) return PLK_OK;
+    std::vector<std::pair<double, double>> spans = it->second.spans;
+    std::sort(spans.begin(), spans.end());
+    double lo = 0, hi = -1;
+    for (const auto& sp : spans) {
+        if (sp.first > hi) { if (hi > lo) *busy_ms += hi - lo; lo = sp.first; hi = sp.second; }
+        else if (sp.second > hi) hi = sp.second;
+    }
+    if (hi > lo) *busy_ms += hi - lo;
     return PLK_OK;
 }
 
@@ -253,7 +276,7 @@ extern "C" int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out
     host::pt r;
     const int32_t rc = msm_wait(ctx, *s, &r);
     s->busy = false;
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     PLK_TRY(rc);
     host::pt_to_affine(r, out_xy, out_is_inf);
     return PLK_OK;
@@ -310,7 +333,7 @@ extern "C" int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[
     host::pt r;
     const int32_t rc = msm_wait(ctx, *s, &r);
     s->busy = false;
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     PLK_TRY(rc);
     host::pt_to_affine(r, w_xy, w_is_inf);
     memcpy(random_v, s->host_rv, 32);
@@ -324,7 +347,7 @@ extern "C" int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t ou
     host::pt r;
     const int32_t rc = msm_wait(ctx, *s, &r);
     s->busy = false;
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     PLK_TRY(rc);
     host::pt_store(r, out_xyzz);
     if (s->kind == 2) {

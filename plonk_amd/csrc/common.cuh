@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/plonk_hip.h"
 #include "g1.cuh"
@@ -34,6 +35,7 @@ struct MsmSegs {
 struct ProfEntry {
     double ms = 0;
     uint64_t launches = 0;
+    std::vector<std::pair<double, double>> spans;   // start, end in ms since the last reset
 };
 struct PendingEvent {
     hipEvent_t e0, e1;
@@ -96,6 +98,7 @@ struct plk_ctx {
     uint32_t* flag_host = nullptr;
     // profiling
     bool profiling = false;
+    hipEvent_t prof_base = nullptr;    // recorded at the last profile reset
     std::map<std::string, plk::ProfEntry> prof;
     std::vector<plk::PendingEvent> pending;
     std::string err;
@@ -118,7 +121,7 @@ int32_t set_err(plk_ctx* ctx, int32_t code, const char* what, hipError_t e, int 
 // profiling brackets (no-ops unless enabled)
 void prof_begin(plk_ctx* ctx, hipStream_t s, const char* name);
 void prof_end(plk_ctx* ctx, hipStream_t s);
-void prof_collect(plk_ctx* ctx);
+void prof_collect(plk_ctx* ctx, bool wait);
 
 int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes);
 

@@ -153,8 +153,9 @@ __device__ __forceinline__ uint32_t acc_run_length(uint32_t n_entries, uint32_t 
     const uint32_t run = (n_entries + lanes_launched - 1) / lanes_launched;
     return run < 1 ? 1 : run;
 }
-template <int WAVES>
-__global__ void __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+// Two waves per SIMD: the loop needs about 170 registers, and more resident waves were measured to add nothing (the kernel
+// is bound by VALU issue, not by latency).
+__global__ void __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tables,
                  uint32_t* __restrict__ tails, uint32_t tail_stride, uint32_t* __restrict__ flushed) {
     const uint32_t lane = blockIdx.x * ACC_THREADS + threadIdx.x;
@@ -355,7 +356,7 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
 // Entries per lane of the accumulation kernel: close to 64, chosen so that the launch is a whole number of chip-wide rounds
 // (256 CUs x 4 SIMDs x 2 waves x 64 lanes), never below 16.
 static uint32_t acc_run(uint64_t max_entries) {
-    static const uint64_t target = getenv("PLK_ACC_RUN") ? (uint64_t)atoi(getenv("PLK_ACC_RUN")) : 64;
+    const uint64_t target = 64;
     const uint64_t chip = 256ull * 4 * 2 * 64;
     uint64_t rounds = (max_entries + chip * target / 2) / (chip * target);
     if (rounds < 1) rounds = 1;
@@ -448,33 +449,22 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     PLK_TRY(tails_reserve(ctx, s, acc_lanes(max_entries, acc_run(max_entries))));
     uint32_t nblocks = (segs.total + 8191) / 8192;
     if (nblocks < 1) nblocks = 1;
-    static const uint32_t max_blocks = getenv("PLK_SORT_BLOCKS") ? (uint32_t)atoi(getenv("PLK_SORT_BLOCKS")) : MSM_MAX_BLOCKS;
-    if (nblocks > max_blocks) nblocks = max_blocks;
+    if (nblocks > (uint32_t)MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
     const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
     hipStream_t st = ctx->st_sort;
-    static const int dbg_skip_sort = getenv("PLK_DBG_SKIP_SORT") ? atoi(getenv("PLK_DBG_SKIP_SORT")) : 0;
-    static int dbg_calls = 0;
     prof_begin(ctx, st, "msm_sort");
-    if (!(dbg_skip_sort && ++dbg_calls > dbg_skip_sort)) {
     hipLaunchKernelGGL(k_msm_count, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts);
     hipLaunchKernelGGL(k_msm_totals, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.totals);
     hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(256), 0, st, s.totals, s.bucket_start);
     hipLaunchKernelGGL(k_msm_offsets, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.bucket_start);
     hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries);
-    }
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.sorted, st));
     st = ctx->st_acc[ctx->acc_turn++ & 1];
     PLK_HIP(hipStreamWaitEvent(st, s.sorted, 0));
     const uint32_t acc_blocks = (uint32_t)((acc_lanes(max_entries, acc_run(max_entries)) + ACC_THREADS - 1) / ACC_THREADS);
     prof_begin(ctx, st, "msm_accumulate");
-    {
-        static const int waves = getenv("PLK_ACC_WAVES") ? atoi(getenv("PLK_ACC_WAVES")) : 2;
-        const dim3 grid(acc_blocks);
-        if (waves == 3) hipLaunchKernelGGL(k_msm_accumulate<3>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
-        else if (waves == 4) hipLaunchKernelGGL(k_msm_accumulate<4>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
-        else hipLaunchKernelGGL(k_msm_accumulate<2>, grid, dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
-    }
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.accumulated, st));
     st = ctx->st_red;
@@ -656,7 +646,7 @@ extern "C" int32_t plk_msm_partial_dev(plk_ctx* ctx, const void* scalars_dev, ui
     const int32_t rc = msm_wait(ctx, s, &r);
     s.busy = false;
     PLK_TRY(rc);
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     host::pt_store(r, out_xyzz);
     return PLK_OK;
 }

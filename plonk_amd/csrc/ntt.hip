@@ -229,7 +229,7 @@ extern "C" int32_t plk_ntt_dev_enqueue(plk_ctx* ctx, void* data_dev, uint32_t lo
 extern "C" int32_t plk_ntt_dev(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen) {
     PLK_TRY(plk_ntt_dev_enqueue(ctx, data_dev, log_n, inverse, coset_gen));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     return PLK_OK;
 }
 extern "C" int32_t plk_ntt(plk_ctx* ctx, uint64_t* data_host, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen) {

@@ -360,7 +360,7 @@ extern "C" int32_t plk_poly_eval_dev(plk_ctx* ctx, const void* coeffs_dev, uint6
     PLK_TRY(division_enqueue(ctx, ctx->stream, (const uint32_t*)coeffs_dev, len, x, nullptr, nullptr, ctx->scratch, ctx->scratch + 8));
     PLK_HIP(hipMemcpyAsync(out, ctx->scratch, 32, hipMemcpyDeviceToHost, ctx->stream));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     return PLK_OK;
 }
 extern "C" int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t x[4], uint64_t out[4]) {
@@ -414,7 +414,7 @@ extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_
     PLK_HIP(hipGetLastError());
     PLK_TRY(ntt_run(ctx, st, (uint32_t*)z_coeffs_out_dev, log_n, true, nullptr));
     PLK_HIP(hipStreamSynchronize(st));
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     return PLK_OK;
 }
 extern "C" int32_t plk_grand_product(plk_ctx* ctx, const uint64_t* witness_flat_host, const uint64_t* sigma_host, uint32_t log_n, const uint64_t beta[4],
@@ -454,7 +454,7 @@ extern "C" int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, 
     hipLaunchKernelGGL(k_any_nonzero, dim3(256), dim3(256), 0, st, t, n * 8, ctx->flag_dev);
     uint32_t flag;
     PLK_TRY(read_flag(ctx, &flag));
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     if (flag & 2u) { ctx->err = "sigma entry out of range"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
     if (flag & 4u) { ctx->err = "permutation constraint: inverse of zero"; return PLK_ERR_INVERSE_OF_ZERO; }
     if (flag & 1u) { ctx->err = "t(X) not divisible by Z_H(X)"; return PLK_ERR_NOT_DIVISIBLE; }
@@ -496,7 +496,7 @@ extern "C" int32_t plk_interpolate_permutation_dev(plk_ctx* ctx, const void* sig
     PLK_TRY(ntt_run(ctx, st, (uint32_t*)s_sigma_out_dev, log_n4, true, nullptr));
     uint32_t flag;
     PLK_TRY(read_flag(ctx, &flag));
-    prof_collect(ctx);
+    prof_collect(ctx, false);
     if (flag & 2u) { ctx->err = "sigma entry outside the permutation domain"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
     return PLK_OK;
 }

@@ -26,7 +26,7 @@ EXPORTS = [
     "plk_grand_product", "plk_grand_product_dev", "plk_quotient", "plk_quotient_dev", "plk_poly_eval", "plk_poly_eval_dev",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
     "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
-    "plk_profile_get",
+    "plk_profile_get", "plk_profile_get_busy",
 ]
 
 
@@ -279,3 +279,8 @@ class Context:
         ms = C.c_double(0); n = C.c_uint64(0)
         self._ck(self.lib.plk_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_get_busy(self, name):
+        ms = C.c_double(0)
+        self._ck(self.lib.plk_profile_get_busy(self.h, name.encode(), C.byref(ms)))
+        return ms.value
