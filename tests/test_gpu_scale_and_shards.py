@@ -95,9 +95,9 @@ def _check_proof_with_trapdoor(orc, proof, zeta, polys, blinds, chal_int, tau_in
         assert pm.kzg_check_with_trapdoor(C, W, ev, rv, zeta_int, chal_int, tau_int, gs_int), f"opening {k}"
 
 
-@pytest.mark.parametrize("log_n", [16, 20])
+@pytest.mark.parametrize("log_n", [16, 20, 22])
 def test_full_size_proof_through_the_trapdoor(orc, log_n):
-    """BASELINE configs[1] and [2]: 2^16 and 2^20 gates on one MI355X.  A proof is uniquely determined by its inputs, so the
+    """BASELINE configs[1], [2] and [3]: 2^16, 2^20 and 2^22 gates on one MI355X.  A proof is uniquely determined by its inputs, so the
     trapdoor identities below pin every commitment, evaluation and opening exactly without a 2^20-point MSM on the CPU."""
     from plonk_amd.prover import ProverKey
     tau_int, gs_int, chal_int = 0x1F2E3D4C5B6A79880123456789ABCDEF1F2E3D4C5B6A7988, 0x0A1B2C3D4E5F60718293A4B5C6D7E8F9, 0x1234567890ABCDEF1122334455667788
@@ -119,6 +119,89 @@ def test_full_size_proof_through_the_trapdoor(orc, log_n):
         assert rc == 0 and res.proof_bytes == want and np.array_equal(ch, res.challenges)
     inputs.close()
     pk.close()
+
+
+def _random_residues(count, seed):
+    """count uniformly random 252-bit values, read as Montgomery residues (every value below r is a valid one)."""
+    raw = np.random.default_rng(seed).integers(0, 1 << 63, size=(count, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << 60) - 1)
+    return raw
+
+
+def test_stress_msm_2p24_through_the_trapdoor(orc):
+    """BASELINE configs[4], MSM half: 2^24 SRS points [tau^i] G with uniformly random scalars (seed 2).  With the trapdoor the
+    answer is (sum_i s_i tau^i) G: one Horner pass on the CPU instead of a 2^24-point MSM."""
+    from plonk_amd.hip import Context
+    tau_int, gs_int = 0x2B3C4D5E6F708192A3B4C5D6E7F8091A2B3C4D5E6F7081, 0x1122334455667788
+    n = 1 << 24
+    ctx = Context(0)
+    tau, gs = synth.to_mont([tau_int, gs_int])
+    ctx.srs_generate(tau, gs, n)
+    sc = _random_residues(n, 2)
+    d = ctx.upload(sc)
+    out, inf = ctx.msm_dev(d, n)
+    f_tau = synth.from_mont(orc.poly_eval(sc, tau))[0]
+    assert orc.point_to_ints(out, inf) == pm.g1_mul(f_tau, pm.G1_GEN)
+    # a window of the same scalars against the middle of the SRS: sum_i s_i tau^(off + i)
+    k, off = (1 << 22) + 12345, (1 << 23) - 777
+    out, inf = ctx.msm_dev(d, k, base_offset=off)
+    want = synth.from_mont(orc.poly_eval(sc[:k], tau))[0] * pow(tau_int, off, pm.R_MOD) % pm.R_MOD
+    assert orc.point_to_ints(out, inf) == pm.g1_mul(want, pm.G1_GEN)
+    ctx.free(d)
+    ctx.close()
+
+
+def test_structured_scalars_through_the_trapdoor(orc):
+    """Scalars a real proof can produce and a uniform sample never does: all equal (every entry of a window lands in one bucket),
+    all zero, +-1, small values, a single non-zero coefficient, the largest digits."""
+    from plonk_amd.hip import Context
+    tau_int, gs_int = 0x1F2E3D4C5B6A79880123456789ABCDEF, 0x0A1B2C3D
+    n = 1 << 16
+    r = pm.R_MOD
+    ctx = Context(0)
+    tau, gs = synth.to_mont([tau_int, gs_int])
+    ctx.srs_generate(tau, gs, n)
+    rng = pm.SplitMix64(77)
+    one_value = rng.next_fr()
+    cases = {
+        "all equal": [one_value] * n,
+        "all zero": [0] * n,
+        "plus and minus one": [1 if i % 3 else r - 1 for i in range(n)],
+        "small": [i % 97 for i in range(n)],
+        "single coefficient": [0] * (n - 1) + [one_value],
+        "extreme digits": [int(("8000", "8001", "7fff", "ffff")[i & 3] * 15, 16) for i in range(n)],   # +2^15, -(2^15 - 1), carries through every window
+        "two buckets": [0x00010001 * (1 + (i & 1)) for i in range(n)],
+    }
+    for name, vals in cases.items():
+        sc = synth.to_mont(vals)
+        out, inf = ctx.msm(sc)
+        want = synth.from_mont(orc.poly_eval(sc, tau))[0]
+        assert orc.point_to_ints(out, inf) == (pm.g1_mul(want, pm.G1_GEN) if want else None), name
+    ctx.close()
+
+
+def test_stress_ntt_2p24_coset_round_trip(orc):
+    """BASELINE configs[4], NTT half: 2^24 uniformly random elements (seed 3), forward coset NTT with g = 5, then the inverse.
+    Three outputs are checked against Horner evaluations f(5 w^k); the round trip must give back every input bit."""
+    from plonk_amd.hip import Context
+    log_n = 24
+    n = 1 << log_n
+    r = pm.R_MOD
+    ctx = Context(0)
+    a = _random_residues(n, 3)
+    d = ctx.upload(a)
+    g5 = synth.to_mont([5])[0]
+    ctx.ntt_dev(d, log_n, coset=g5)
+    vals = ctx.download(d, (n, 4))
+    w = pow(5, (r - 1) // n, r)
+    for k in (0, 1, 0xABCDEF, n - 1):
+        x = synth.to_mont([5 * pow(w, k, r) % r])[0]
+        assert np.array_equal(vals[k], orc.poly_eval(a, x)), k
+    ctx.ntt_dev(d, log_n, inverse=True, coset=g5)
+    back = ctx.download(d, (n, 4))
+    assert np.array_equal(back, a)
+    ctx.free(d)
+    ctx.close()
 
 
 def test_two_logical_shards_on_one_device(orc):
