@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--cpu-log-gates", type=int, default=16, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL over xGMI, one rank per GPU) or gloo (rehearsal with several ranks on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,8 +88,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            gather_device = torch.device("cuda", local_rank)
+        else:   # rehearsal on fewer GPUs than ranks: the partial sums travel through host memory
+            dist.init_process_group(backend=args.dist_backend)
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            gather_device = torch.device("cpu")
 
     from plonk_amd import synth
     from plonk_amd.prover import ProverKey
@@ -108,13 +115,17 @@ def main():
     count = max(0, min(per, total - first))
     pk.generate_srs(tau, gscal, total, shard_first=first, shard_len=count)
     if world > 1:
-        send = torch.empty(16, dtype=torch.int64, device="cuda")
-        recv = torch.empty(16 * world, dtype=torch.int64, device="cuda")
+        bufs = {}
 
         def gather(mine):
-            send.copy_(torch.from_numpy(mine.view(np.int64)))
+            count = mine.shape[0]
+            if count not in bufs:
+                bufs[count] = (torch.empty(16 * count, dtype=torch.int64, device=gather_device),
+                               torch.empty(16 * count * world, dtype=torch.int64, device=gather_device))
+            send, recv = bufs[count]
+            send.copy_(torch.from_numpy(mine.view(np.int64).reshape(-1)))
             dist.all_gather_into_tensor(recv, send)
-            return recv.cpu().numpy().view(np.uint64).reshape(world, 16)
+            return recv.cpu().numpy().view(np.uint64).reshape(world, count, 16)
         pk.set_sharding(rank, world, gather)
     pk.set_opening_challenge(synth.to_mont([0x1234567890ABCDEF1122334455667788])[0])
     inputs = pk.prepare(tables)
@@ -124,7 +135,8 @@ def main():
     def sync():
         pk.ctx.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if args.dist_backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -140,7 +152,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=gather_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

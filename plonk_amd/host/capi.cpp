@@ -34,10 +34,10 @@ int32_t plonk_pk_generate(void* pk, const uint64_t* tau, const uint64_t* gscal, 
     return guarded([&] { Fr t, g; memcpy(t.v, tau, 32); memcpy(g.v, gscal, 32); static_cast<KZGProverKey*>(pk)->generate_shard(t, g, first, count, len); });
 }
 int32_t plonk_pk_set_opening_challenge(void* pk, const uint64_t* c) { return guarded([&] { memcpy(static_cast<KZGProverKey*>(pk)->opening_challenge.v, c, 32); }); }
-// gather(user, mine[16], all[world*16])
-typedef void (*plonk_gather_fn)(void* user, const uint64_t* mine, uint64_t* all);
+// gather(user, mine[count][16], count, all[world][count][16])
+typedef void (*plonk_gather_fn)(void* user, const uint64_t* mine, uint64_t count, uint64_t* all);
 int32_t plonk_pk_set_sharding(void* pk, uint32_t rank, uint32_t world, plonk_gather_fn fn, void* user) {
-    return guarded([&] { static_cast<KZGProverKey*>(pk)->set_sharding(rank, world, [fn, user](const uint64_t* m, uint64_t* a) { fn(user, m, a); }); });
+    return guarded([&] { static_cast<KZGProverKey*>(pk)->set_sharding(rank, world, [fn, user](const uint64_t* m, uint64_t k, uint64_t* a) { fn(user, m, k, a); }); });
 }
 
 // polys: a, b, c, q_add, q_mul, s_id, s_sigma (coefficients, any trailing zeros are stripped as from_coefficients_vec does)

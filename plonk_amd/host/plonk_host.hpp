@@ -70,9 +70,10 @@ struct Domain {
 // stands for `rng: &mut R`: every call is one Fr::rand(rng)
 using Rng = std::function<Fr()>;
 
-// Collective used when the SRS is sharded over several GPUs: gathers every rank's 16-limb partial point
-// (X, Y, ZZ, ZZZ) into all[world_size][16].  Single-GPU provers pass nothing.
-using AllGather = std::function<void(const uint64_t* mine, uint64_t* all)>;
+// Collective used when the SRS is sharded over several GPUs: gathers every rank's `count` partial points (16 limbs each:
+// X, Y, ZZ, ZZZ) into all[world_size][count][16].  The prover calls it once per round (7, 1, 1 and 9 points), not once per
+// commitment.  Single-GPU provers pass nothing.
+using AllGather = std::function<void(const uint64_t* mine, uint64_t count, uint64_t* all)>;
 
 // KZGProverKey (src/prover.rs:32): owns a plk_ctx with the powers resident in HBM.
 class KZGProverKey {

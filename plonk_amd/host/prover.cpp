@@ -84,22 +84,32 @@ DeviceInputs::~DeviceInputs() {
 
 namespace {
 
-G1Affine finish_point(const KZGProverKey& pk, int32_t ticket, bool is_open, Fr* random_v, Fr* eval) {
+// Ends `count` tickets and returns their points.  With a sharded SRS every ticket yields this rank's partial sum; all partial sums
+// of the call travel in one collective and are added on the host (EC addition is not an RCCL reduction).
+void finish_points(const KZGProverKey& pk, const int32_t* tickets, int count, bool is_open, G1Affine* out, Fr* random_v, Fr* eval) {
     plk_ctx* ctx = pk.ctx();
-    G1Affine out;
     if (pk.world_size <= 1) {
-        if (is_open) check(ctx, plk_kzg_open_end(ctx, ticket, out.xy, &out.infinity, random_v->v, eval->v));
-        else check(ctx, plk_kzg_commit_end(ctx, ticket, out.xy, &out.infinity));
-        return out;
+        for (int i = 0; i < count; ++i) {
+            if (is_open) check(ctx, plk_kzg_open_end(ctx, tickets[i], out[i].xy, &out[i].infinity, random_v[i].v, eval[i].v));
+            else check(ctx, plk_kzg_commit_end(ctx, tickets[i], out[i].xy, &out[i].infinity));
+        }
+        return;
     }
-    // sharded SRS: this rank holds a partial sum; gather all partials and add them (EC addition is not an RCCL reduction)
-    uint64_t mine[16];
-    Fr rv{}, ev{};
-    check(ctx, plk_kzg_end_partial(ctx, ticket, mine, rv.v, ev.v));
-    std::vector<uint64_t> all((size_t)16 * pk.world_size);
-    pk.gather(mine, all.data());
-    check(ctx, plk_g1_sum_partials(all.data(), pk.world_size, out.xy, &out.infinity));
-    if (is_open) { *random_v = rv; *eval = ev; }
+    std::vector<uint64_t> mine((size_t)16 * count), all((size_t)16 * count * pk.world_size), one((size_t)16 * pk.world_size);
+    for (int i = 0; i < count; ++i) {
+        Fr rv{}, ev{};
+        check(ctx, plk_kzg_end_partial(ctx, tickets[i], &mine[(size_t)16 * i], rv.v, ev.v));
+        if (is_open) { random_v[i] = rv; eval[i] = ev; }
+    }
+    pk.gather(mine.data(), (uint64_t)count, all.data());
+    for (int i = 0; i < count; ++i) {
+        for (uint32_t r = 0; r < pk.world_size; ++r) memcpy(&one[(size_t)16 * r], &all[((size_t)r * count + i) * 16], 128);
+        check(ctx, plk_g1_sum_partials(one.data(), pk.world_size, out[i].xy, &out[i].infinity));
+    }
+}
+G1Affine finish_point(const KZGProverKey& pk, int32_t ticket) {
+    G1Affine out;
+    finish_points(pk, &ticket, 1, false, &out, nullptr, nullptr);
     return out;
 }
 
@@ -136,7 +146,9 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
             const int i = order[k];
             check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
         }
-        for (int i = 0; i < 7; ++i) comm[i].comm = finish_point(pk, ticket[i], false, nullptr, nullptr);
+        G1Affine c7[7];
+        finish_points(pk, ticket, 7, false, c7, nullptr, nullptr);
+        for (int i = 0; i < 7; ++i) comm[i].comm = c7[i];
     }
     transcript.absorb_commitment("q_add", proof.comm_q_add);                    // :168-194
     transcript.absorb_commitment("q_mul", proof.comm_q_mul);
@@ -175,13 +187,13 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
         for (auto& r : blind[8]) r = rng();
         check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));
     } catch (...) {
-        finish_point(pk, z_ticket, false, nullptr, nullptr);
+        finish_point(pk, z_ticket);
         throw;
     }
-    comm[7].comm = finish_point(pk, z_ticket, false, nullptr, nullptr);
+    comm[7].comm = finish_point(pk, z_ticket);
     transcript.absorb_commitment("z", proof.comm_z);                           // :214-216
     const Fr alpha = transcript.challenge_alpha();                              // :219 (enters only the public-input term, which is empty)
-    comm[8].comm = finish_point(pk, t_ticket, false, nullptr, nullptr);
+    comm[8].comm = finish_point(pk, t_ticket);
     transcript.absorb_commitment("t", proof.comm_t);                           // :257-259
     const Fr zeta = transcript.challenge_zeta();                                // :262
     lap(2);
@@ -198,7 +210,10 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
             const int i = order[k];
             check(ctx, plk_kzg_open_begin(ctx, polys[i], lens[i], &blind[i][0].v[0], zeta.v, pk.opening_challenge.v, &ticket[i]));
         }
-        for (int i = 0; i < 9; ++i) open[i].w = finish_point(pk, ticket[i], true, &open[i].random_v, &eval[i]);
+        G1Affine w9[9];
+        Fr rv9[9];
+        finish_points(pk, ticket, 9, true, w9, rv9, eval);
+        for (int i = 0; i < 9; ++i) { open[i].w = w9[i]; open[i].random_v = rv9[i]; }
     }
     transcript.absorb_evaluations(proof.eval_a, proof.eval_b, proof.eval_c, proof.eval_q_add, proof.eval_q_mul, proof.eval_s_id, proof.eval_s_sigma,
                                   proof.eval_z, proof.eval_t);                  // :277-282

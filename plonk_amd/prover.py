@@ -21,7 +21,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "lib", "libplonk_host.so")
 HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate",
                 "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
                 "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1"]
-GATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+GATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64))
 
 _host = None
 
@@ -115,11 +115,12 @@ class ProverKey:
         self._ck(self.lib.plonk_pk_set_opening_challenge(self.h, _ptr(_u64(chal, (4,)))))
 
     def set_sharding(self, rank, world_size, gather):
-        """gather(mine: np.ndarray(16,) uint64) -> np.ndarray(world_size, 16): all ranks' partial points."""
-        def cb(_user, mine, out):
-            m = np.ctypeslib.as_array(mine, shape=(16,)).copy()
-            res = np.ascontiguousarray(gather(m), dtype=np.uint64).reshape(world_size * 16)
-            C.memmove(out, res.ctypes.data, world_size * 16 * 8)
+        """gather(mine: np.ndarray(count, 16) uint64) -> np.ndarray(world_size, count, 16): the partial points of all ranks.
+        Called once per prover round (count = 7, 1, 1, 9)."""
+        def cb(_user, mine, count, out):
+            m = np.ctypeslib.as_array(mine, shape=(count, 16)).copy()
+            res = np.ascontiguousarray(gather(m), dtype=np.uint64).reshape(world_size * count * 16)
+            C.memmove(out, res.ctypes.data, world_size * count * 16 * 8)
         self._cb = GATHER_FN(cb)
         self._ck(self.lib.plonk_pk_set_sharding(self.h, C.c_uint32(rank), C.c_uint32(world_size), self._cb, None))
 

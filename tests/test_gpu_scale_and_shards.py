@@ -242,7 +242,7 @@ pk = ProverKey(0)
 tau, gs = synth.seeded_scalars(2, 7)
 pk.generate_srs(tau, gs, total, shard_first=rank * per, shard_len=min(per, total - rank * per))
 def gather(mine):
-    recv = [torch.zeros(16, dtype=torch.int64) for _ in range(world)]
+    recv = [torch.zeros(mine.shape, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(recv, torch.from_numpy(mine.view(np.int64)))
     return np.stack([r.numpy().view(np.uint64) for r in recv])
 pk.set_sharding(rank, world, gather)
