@@ -86,6 +86,195 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint32_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------ sizes >= 2^11
+// Same Stockham passes, different inner structure.  A workgroup of 256 threads owns T * R = 2048 elements (72 KB of LDS, two
+// workgroups per CU so that one loads or stores while the other computes).  Every thread keeps eight elements in registers and
+// runs up to three butterfly stages on them between two visits to LDS: the first three stages work on the values as they arrive
+// from HBM, the last ones hand their results straight to the store.  The multiplication that brings a lazily reduced value back
+// below 2p before it is stored carries the factor the NEXT pass would apply on load (w_{Ns' R'}^{(j mod Ns') t}), or n^-1 in
+// the final pass of an inverse transform, so loads never multiply.  Twiddles of the butterfly stages come from a per-pass table
+// w_R^e (e < R/2) in LDS.  Stages whose twiddle is 1 (all of stage 1, half of stage 2, a quarter of stage 3) skip the product.
+//
+// Bounds (fp29.cuh vocabulary).  Loaded values: normalized, bound 2.  First three stages: at most bound 16, limbs < 3.5 * 2^30.
+// Every later stage adds 2 to the bound and 2^30 to the limbs; values are normalized whenever they go to LDS, so a product never
+// sees an operand limb above 2.5 * 2^30 < 2^31.6, and the bound stays below 16 + 2 * 6 = 28 (times 2 for the twiddle: 56 <= 169).
+constexpr int NTT8_TILE = 2048;
+constexpr int NTT8_THREADS = 256;
+constexpr int NTT8_MAX_LOG_R = 8;   // 2048 * 36 B of data + 128 * 36 B of twiddles: two workgroups fit the 160 KB of a CU
+
+struct Ntt8Pass {
+    uint32_t log_n, log_r, log_ns, log_t;
+    uint32_t nsub, q[4];        // butterfly stages per visit of the registers; q[0] == 3, sum == log_r
+    uint32_t next_log_r;        // radix of the following pass, 0 in the last pass
+    int32_t inverse, use_scale;
+};
+
+// w^e (inverse: w^-e) as a multiplication operand: bound 2, limbs < 2^31 (2p - w is left unnormalized)
+__device__ __forceinline__ fe twiddle_operand(const uint32_t* __restrict__ W, uint32_t e, uint32_t log_n, int inverse) {
+    const uint32_t n = 1u << log_n, half = n >> 1;
+    if (inverse) e = (n - e) & (n - 1);
+    const bool neg = e >= half;
+    if (neg) e -= half;
+    fe w = ld_fe(W + 8ull * e);
+    if (neg) w = sub2<FrP>(fe_zero(), w);
+    return w;
+}
+
+// stages 1..3 on positions 0..7 of a group whose twiddles are the constants 1, w_4, w_8, w_8^2, w_8^3
+__device__ __forceinline__ void ntt8_first_stages(fe* x, const uint32_t* tw, uint32_t log_r) {
+#pragma unroll
+    for (int a = 0; a < 8; a += 2) {                      // stage 1: twiddle 1
+        const fe u = x[a], v = x[a + 1];
+        x[a] = add(u, v);
+        x[a + 1] = sub2<FrP>(u, v);                       // v normalized, bound 2
+    }
+#pragma unroll
+    for (int a = 0; a < 8; a += 4) {                      // stage 2
+        {
+            const fe u = x[a];
+            fe v = x[a + 2];
+            norm(v);                                      // bound 4
+            x[a] = add(u, v);
+            x[a + 2] = sub4<FrP>(u, v);
+        }
+        {
+            const fe u = x[a + 1];
+            const fe t = mul<FrP>(x[a + 3], lds_get(tw, 1u << (log_r - 2)));
+            x[a + 1] = add(u, t);
+            x[a + 3] = sub2<FrP>(u, t);
+        }
+    }
+    {                                                     // stage 3
+        const fe u = x[0];
+        fe v = x[4];
+        norm(v);                                          // bound 8
+        x[0] = add(u, v);
+        x[4] = sub8<FrP>(u, v);
+    }
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const fe u = x[i];
+        const fe t = mul<FrP>(x[i + 4], lds_get(tw, (uint32_t)i << (log_r - 3)));
+        x[i] = add(u, t);
+        x[i + 4] = sub2<FrP>(u, t);
+    }
+}
+
+// stage s+D+1 of a group of 2^Q elements x[0..2^Q) at positions base + m 2^s; base_low = base mod 2^s
+template <int Q, int D>
+__device__ __forceinline__ void ntt8_stage(fe* x, const uint32_t* tw, uint32_t base_low, uint32_t s, uint32_t log_r) {
+#pragma unroll
+    for (int low = 0; low < (1 << D); ++low) {
+        const uint32_t i = base_low + ((uint32_t)low << s);
+        const fe w = lds_get(tw, i << (log_r - s - D - 1));
+#pragma unroll
+        for (int hi = 0; hi < (1 << (Q - D - 1)); ++hi) {
+            const int m0 = (hi << (D + 1)) | low, m1 = m0 | (1 << D);
+            const fe u = x[m0];
+            const fe t = mul<FrP>(x[m1], w);
+            x[m0] = add(u, t);
+            x[m1] = sub2<FrP>(u, t);
+        }
+    }
+}
+template <int Q>
+__device__ __forceinline__ void ntt8_stages(fe* x, const uint32_t* tw, uint32_t base_low, uint32_t s, uint32_t log_r) {
+    ntt8_stage<Q, 0>(x, tw, base_low, s, log_r);
+    if constexpr (Q > 1) ntt8_stage<Q, 1>(x, tw, base_low, s, log_r);
+    if constexpr (Q > 2) ntt8_stage<Q, 2>(x, tw, base_low, s, log_r);
+}
+
+// one visit of the registers after the first: every thread takes 8 >> Q groups of 2^Q elements, one after the other
+template <int Q>
+__device__ __forceinline__ void ntt8_subpass(uint32_t* lds, const uint32_t* tw, const Ntt8Pass& a, uint32_t s, bool final_sub, const uint32_t* __restrict__ W,
+                                             uint32_t* __restrict__ out, const fe& sc) {
+    constexpr int G = 8 >> Q, E = 1 << Q;
+    const uint32_t log_t = a.log_t, T = 1u << log_t, log_r = a.log_r, ns_mask = (1u << a.log_ns) - 1;
+#pragma unroll 1
+    for (int c = 0; c < G; ++c) {
+        const uint32_t gid = threadIdx.x + c * NTT8_THREADS;
+        uint32_t jj, gpos;
+        if (final_sub && a.log_ns == 0) { gpos = gid & ((1u << (log_r - Q)) - 1); jj = gid >> (log_r - Q); }   // stores run along u
+        else { jj = gid & (T - 1); gpos = gid >> log_t; }                                                      // stores run along j
+        const uint32_t base_low = gpos & ((1u << s) - 1);
+        const uint32_t pos0 = ((gpos >> s) << (s + Q)) | base_low;
+        fe x[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) x[m] = lds_get(lds, ((pos0 + ((uint32_t)m << s)) << log_t) + jj);
+        ntt8_stages<Q>(x, tw, base_low, s, log_r);
+#pragma unroll
+        for (int m = 0; m < E; ++m) norm(x[m]);
+        if (!final_sub) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) lds_put(lds, ((pos0 + ((uint32_t)m << s)) << log_t) + jj, x[m]);
+            continue;
+        }
+        const uint64_t j = (uint64_t)blockIdx.x * T + jj;
+        const uint64_t j0 = ((j >> a.log_ns) << (a.log_ns + log_r)) | (j & ns_mask);
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const uint32_t u = pos0 + ((uint32_t)m << s);
+            const uint64_t o = j0 + ((uint64_t)u << a.log_ns);
+            uint32_t* dst = out + 8ull * o;
+            if (a.next_log_r == 0) {
+                st_fe<FrP>(dst, mul<FrP>(x[m], sc));
+            } else {
+                const uint32_t lns2 = a.log_ns + log_r;
+                const uint32_t t2 = (uint32_t)(o >> (a.log_n - a.next_log_r)), k2 = (uint32_t)o & ((1u << lns2) - 1);
+                fe w = sc;   // 1
+                if (t2 != 0 && k2 != 0) w = twiddle_operand(W, (k2 * t2) << (a.log_n - lns2 - a.next_log_r), a.log_n, a.inverse);
+                const fe y = mul<FrP>(x[m], w);
+                uint32_t wd[8];
+                pack(y, wd);
+                store8(dst, wd);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NTT8_THREADS) k_ntt_pass8(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ W, Ntt8Pass a,
+                                                            NttScale scale /* x*2^256 words */) {
+    __shared__ uint32_t lds[NTT8_TILE * 9];
+    __shared__ uint32_t tw[(1 << (NTT8_MAX_LOG_R - 1)) * 9];
+    const uint32_t log_r = a.log_r, log_t = a.log_t, T = 1u << log_t;
+    for (uint32_t e = threadIdx.x; e < (1u << (log_r - 1)); e += NTT8_THREADS) {
+        fe w = twiddle_operand(W, e << (a.log_n - log_r), a.log_n, a.inverse);
+        norm(w);
+        lds_put(tw, e, w);
+    }
+    {
+        fe x[8];
+        const uint32_t jj = threadIdx.x & (T - 1), g = threadIdx.x >> log_t;   // g < R / 8: low bits of the row index
+        const uint64_t j = (uint64_t)blockIdx.x * T + jj;
+        const uint32_t log_stride = a.log_n - log_r;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const uint32_t t = ((uint32_t)(((m & 1) << 2) | (m & 2) | (m >> 2)) << (log_r - 3)) | g;   // position m of the group holds row brev3(m) R/8 + g
+            x[m] = ld_fe(in + 8ull * (j + ((uint64_t)t << log_stride)));
+        }
+        __syncthreads();   // twiddle table complete
+        ntt8_first_stages(x, tw, log_r);
+        const uint32_t pos_hi = log_r > 3 ? (__brev(g) >> (32 - (log_r - 3))) : 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            norm(x[m]);
+            lds_put(lds, (((pos_hi << 3) | (uint32_t)m) << log_t) + jj, x[m]);
+        }
+    }
+    __syncthreads();
+    const fe sc = a.use_scale ? mul<FrP>(unpack(scale.w), fe_const(FrP::TO_RP)) : fe_const(FrP::ONE);
+    uint32_t s = 3;
+    for (uint32_t sp = 1; sp < a.nsub; ++sp) {
+        const bool final_sub = sp + 1 == a.nsub;
+        const uint32_t q = a.q[sp];
+        if (q == 3) ntt8_subpass<3>(lds, tw, a, s, final_sub, W, out, sc);
+        else if (q == 2) ntt8_subpass<2>(lds, tw, a, s, final_sub, W, out, sc);
+        else ntt8_subpass<1>(lds, tw, a, s, final_sub, W, out, sc);
+        s += q;
+        if (!final_sub) __syncthreads();
+    }
+}
+
 // W[i] = w^i for i < n/2 from pow2[k] = w^(2^k) (x*2^256 words)
 __global__ void __launch_bounds__(256) k_ntt_twiddles(uint32_t* __restrict__ W, uint32_t half, const uint32_t* __restrict__ pow2) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -166,20 +355,18 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
     if (log_n == 0) return PLK_OK;
     const uint32_t* W;
     PLK_TRY(ntt_twiddles(ctx, log_n, &W));
-    // pass plan
-    uint32_t lr[3], lns[3], lt[3], npass;
+    // pass plan: radices as even as possible, at most 2^10 per pass below 2^11 elements (k_ntt_pass), 2^8 from there on (k_ntt_pass8)
+    const bool big = log_n >= 11;
+    uint32_t lr[4], lns[4], lt[4], npass;
     if (log_n <= 10) { npass = 1; lr[0] = log_n; lns[0] = 0; lt[0] = 0; }
     else {
-        npass = (log_n + 9) / 10;
+        npass = (log_n + NTT8_MAX_LOG_R - 1) / NTT8_MAX_LOG_R;
         const uint32_t base = log_n / npass, rem = log_n % npass;
         uint32_t acc = 0;
         for (uint32_t p = 0; p < npass; ++p) {
             lr[p] = base + (p < rem ? 1 : 0);
             lns[p] = acc;
-            uint32_t t = 12 - lr[p];
-            if (t > log_n - lr[p]) t = log_n - lr[p];
-            if (p > 0 && t > acc) t = acc;
-            lt[p] = t;
+            lt[p] = 11 - lr[p];
             acc += lr[p];
         }
     }
@@ -203,9 +390,24 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
     for (uint32_t p = 0; p < npass; ++p) {
         const bool last = p + 1 == npass;
         uint32_t* dst = last ? data : ctx->ntt_tmp[p & 1];
-        const uint32_t groups = (uint32_t)(n >> (lr[p] + lt[p]));
-        hipLaunchKernelGGL(k_ntt_pass, dim3(groups), dim3(NTT_THREADS), 0, st, src, dst, W, log_n, lr[p], lns[p], lt[p], inverse ? 1 : 0, last ? 1 : 0,
-                           (last && inverse) ? 1 : 0, ninv);
+        if (!big) {
+            hipLaunchKernelGGL(k_ntt_pass, dim3(1), dim3(NTT_THREADS), 0, st, src, dst, W, log_n, lr[p], lns[p], lt[p], inverse ? 1 : 0, last ? 1 : 0,
+                               (last && inverse) ? 1 : 0, ninv);
+        } else {
+            Ntt8Pass a;
+            a.log_n = log_n; a.log_r = lr[p]; a.log_ns = lns[p]; a.log_t = lt[p];
+            a.next_log_r = last ? 0 : lr[p + 1];
+            a.inverse = inverse ? 1 : 0; a.use_scale = (last && inverse) ? 1 : 0;
+            // three stages per visit of the registers, the remainder as 2 or 2 + 2
+            uint32_t left = lr[p] - 3;
+            a.nsub = 1; a.q[0] = 3; a.q[1] = a.q[2] = a.q[3] = 0;
+            while (left > 0) {
+                const uint32_t q = (left == 4 || left == 2) ? 2 : (left >= 3 ? 3 : 1);
+                a.q[a.nsub++] = q;
+                left -= q;
+            }
+            hipLaunchKernelGGL(k_ntt_pass8, dim3((uint32_t)(n / NTT8_TILE)), dim3(NTT8_THREADS), 0, st, src, dst, W, a, ninv);
+        }
         src = dst;
     }
     prof_end(ctx, st);
