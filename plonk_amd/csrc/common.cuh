@@ -89,6 +89,7 @@ struct plk_ctx {
     uint32_t* tables = nullptr;        // [MSM_WINDOWS][table_stride] affine, 16 words each, x*2^261 form
     // NTT
     std::map<int, uint32_t*> twiddles; // log_n -> w^i for i < n/2, x*2^261 form
+    std::map<std::vector<uint64_t>, uint32_t*> coset_factors;   // (log_n, inverse, generator) -> g^i, or n^-1 g^-i, i < n (x*2^261 form)
     uint32_t* ntt_tmp[2] = {nullptr, nullptr};
     uint64_t ntt_tmp_cap = 0;
     // scratch for pointwise / scan kernels

@@ -185,9 +185,9 @@ __device__ __forceinline__ void ntt8_stages(fe* x, const uint32_t* tw, uint32_t 
 }
 
 // one visit of the registers after the first: every thread takes 8 >> Q groups of 2^Q elements, one after the other
-template <int Q>
+template <int Q, bool OUT_F>
 __device__ __forceinline__ void ntt8_subpass(uint32_t* lds, const uint32_t* tw, const Ntt8Pass& a, uint32_t s, bool final_sub, const uint32_t* __restrict__ W,
-                                             uint32_t* __restrict__ out, const fe& sc) {
+                                             uint32_t* __restrict__ out, const fe& sc, const uint32_t* __restrict__ out_factors) {
     constexpr int G = 8 >> Q, E = 1 << Q;
     const uint32_t log_t = a.log_t, T = 1u << log_t, log_r = a.log_r, ns_mask = (1u << a.log_ns) - 1;
 #pragma unroll 1
@@ -217,7 +217,8 @@ __device__ __forceinline__ void ntt8_subpass(uint32_t* lds, const uint32_t* tw, 
             const uint64_t o = j0 + ((uint64_t)u << a.log_ns);
             uint32_t* dst = out + 8ull * o;
             if (a.next_log_r == 0) {
-                st_fe<FrP>(dst, mul<FrP>(x[m], sc));
+                if constexpr (OUT_F) st_fe<FrP>(dst, mul<FrP>(x[m], ld_fe(out_factors + 8ull * o)));   // inverse coset: n^-1 g^-o
+                else st_fe<FrP>(dst, mul<FrP>(x[m], sc));
             } else {
                 const uint32_t lns2 = a.log_ns + log_r;
                 const uint32_t t2 = (uint32_t)(o >> (a.log_n - a.next_log_r)), k2 = (uint32_t)o & ((1u << lns2) - 1);
@@ -232,8 +233,12 @@ __device__ __forceinline__ void ntt8_subpass(uint32_t* lds, const uint32_t* tw, 
     }
 }
 
+// IN_F: multiply by in_factors[i] while loading (first pass of a forward coset transform); OUT_F: the final product takes
+// out_factors[o] instead of the scale (last pass of an inverse coset transform)
+template <bool IN_F, bool OUT_F>
 __global__ void __launch_bounds__(NTT8_THREADS) k_ntt_pass8(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ W, Ntt8Pass a,
-                                                            NttScale scale /* x*2^256 words */) {
+                                                            NttScale scale /* x*2^256 words */, const uint32_t* __restrict__ in_factors,
+                                                            const uint32_t* __restrict__ out_factors) {
     __shared__ uint32_t lds[NTT8_TILE * 9];
     __shared__ uint32_t tw[(1 << (NTT8_MAX_LOG_R - 1)) * 9];
     const uint32_t log_r = a.log_r, log_t = a.log_t, T = 1u << log_t;
@@ -247,11 +252,17 @@ __global__ void __launch_bounds__(NTT8_THREADS) k_ntt_pass8(const uint32_t* __re
         const uint32_t jj = threadIdx.x & (T - 1), g = threadIdx.x >> log_t;   // g < R / 8: low bits of the row index
         const uint64_t j = (uint64_t)blockIdx.x * T + jj;
         const uint32_t log_stride = a.log_n - log_r;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const uint32_t t = ((uint32_t)(((m & 1) << 2) | (m & 2) | (m >> 2)) << (log_r - 3)) | g;   // position m of the group holds row brev3(m) R/8 + g
-            x[m] = ld_fe(in + 8ull * (j + ((uint64_t)t << log_stride)));
+        // position m of the group holds row brev3(m) R/8 + g.  Written out eight times: with the coset product inside, the compiler
+        // keeps a loop here and moves x[] to scratch memory.
+#define NTT8_LOAD(m)                                                                                                          \
+        {                                                                                                                     \
+            const uint32_t t = ((uint32_t)((((m) & 1) << 2) | ((m) & 2) | ((m) >> 2)) << (log_r - 3)) | g;                     \
+            const uint64_t at = j + ((uint64_t)t << log_stride);                                                              \
+            if constexpr (IN_F) x[m] = mul<FrP>(ld_fe(in + 8ull * at), ld_fe(in_factors + 8ull * at)); /* coset: x_i g^i */   \
+            else x[m] = ld_fe(in + 8ull * at);                                                                                \
         }
+        NTT8_LOAD(0) NTT8_LOAD(1) NTT8_LOAD(2) NTT8_LOAD(3) NTT8_LOAD(4) NTT8_LOAD(5) NTT8_LOAD(6) NTT8_LOAD(7)
+#undef NTT8_LOAD
         __syncthreads();   // twiddle table complete
         ntt8_first_stages(x, tw, log_r);
         const uint32_t pos_hi = log_r > 3 ? (__brev(g) >> (32 - (log_r - 3))) : 0;
@@ -267,9 +278,9 @@ __global__ void __launch_bounds__(NTT8_THREADS) k_ntt_pass8(const uint32_t* __re
     for (uint32_t sp = 1; sp < a.nsub; ++sp) {
         const bool final_sub = sp + 1 == a.nsub;
         const uint32_t q = a.q[sp];
-        if (q == 3) ntt8_subpass<3>(lds, tw, a, s, final_sub, W, out, sc);
-        else if (q == 2) ntt8_subpass<2>(lds, tw, a, s, final_sub, W, out, sc);
-        else ntt8_subpass<1>(lds, tw, a, s, final_sub, W, out, sc);
+        if (q == 3) ntt8_subpass<3, OUT_F>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
+        else if (q == 2) ntt8_subpass<2, OUT_F>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
+        else ntt8_subpass<1, OUT_F>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
         s += q;
         if (!final_sub) __syncthreads();
     }
@@ -296,6 +307,21 @@ __global__ void __launch_bounds__(256) k_scale_powers(uint32_t* __restrict__ dat
     const fe g = mul<FrP>(ld_fe(pow2), to_rp);
     for (int k = 0; k < 8 && i0 + k < n; ++k) {
         st_fe<FrP>(data + 8 * (i0 + k), mul<FrP>(ld_fe(data + 8 * (i0 + k)), cur));
+        cur = mul<FrP>(cur, g);
+    }
+}
+
+// out[i] = base * g^i in the 2^261 form (a multiplication operand that keeps the other factor's form).  Inputs as in k_scale_powers.
+__global__ void __launch_bounds__(256) k_power_table(uint32_t* __restrict__ out, uint64_t n, const uint32_t* __restrict__ pow2, const uint32_t* __restrict__ base) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    const fe to_rp = fe_const(FrP::TO_RP);
+    fe cur = mul<FrP>(ld_fe(base), to_rp);
+    for (int k = 0; k < 40; ++k)
+        if ((i0 >> k) & 1) cur = mul<FrP>(cur, mul<FrP>(ld_fe(pow2 + 8 * k), to_rp));
+    const fe g = mul<FrP>(ld_fe(pow2), to_rp);
+    for (int k = 0; k < 8 && i0 + k < n; ++k) {
+        st_fe<FrP>(out + 8 * (i0 + k), cur);
         cur = mul<FrP>(cur, g);
     }
 }
@@ -329,6 +355,8 @@ int32_t ntt_twiddles(plk_ctx* ctx, uint32_t log_n, const uint32_t** out) {
 void ntt_release(plk_ctx* ctx) {
     for (auto& kv : ctx->twiddles) hipFree(kv.second);
     ctx->twiddles.clear();
+    for (auto& kv : ctx->coset_factors) hipFree(kv.second);
+    ctx->coset_factors.clear();
     hipFree(ctx->ntt_tmp[0]); hipFree(ctx->ntt_tmp[1]);
     ctx->ntt_tmp[0] = ctx->ntt_tmp[1] = nullptr; ctx->ntt_tmp_cap = 0;
 }
@@ -346,6 +374,36 @@ static int32_t scale_powers(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint64
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(st));
     PLK_HIP(hipFree(dev));
+    return PLK_OK;
+}
+
+// Per-element factors of a coset transform of 2^log_n >= 2^11 elements, built once per (size, direction, generator) and kept:
+// forward g^i (applied while the first pass loads), inverse n^-1 g^-i (applied while the last pass stores).
+static int32_t coset_factors(plk_ctx* ctx, hipStream_t st, uint32_t log_n, bool inverse, const uint64_t* gen, const uint32_t** out) {
+    std::vector<uint64_t> key = {log_n, inverse ? 1ull : 0ull, gen[0], gen[1], gen[2], gen[3]};
+    auto it = ctx->coset_factors.find(key);
+    if (it != ctx->coset_factors.end()) { *out = it->second; return PLK_OK; }
+    const uint64_t n = 1ull << log_n;
+    host::el g = host::el_load(gen), base = host::one(host::FR);
+    if (inverse) {
+        if (host::is_zero(g)) { ctx->err = "coset generator is zero"; return PLK_ERR_INVERSE_OF_ZERO; }
+        g = host::inv(host::FR, g);
+        base = host::inv(host::FR, host::from_u64(host::FR, n));
+    }
+    uint64_t buf[41 * 4];
+    host::el p = g;
+    for (int k = 0; k < 40; ++k) { memcpy(buf + 4 * k, p.v, 32); p = host::mul(host::FR, p, p); }
+    memcpy(buf + 160, base.v, 32);
+    uint32_t *dev = nullptr, *table = nullptr;
+    PLK_HIP(hipMalloc(&dev, sizeof(buf)));
+    if (hipMalloc(&table, n * 32) != hipSuccess) { hipFree(dev); ctx->err = "out of device memory for the coset factors"; return PLK_ERR_ALLOC; }
+    PLK_HIP(hipMemcpyAsync(dev, buf, sizeof(buf), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_power_table, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, table, n, dev, dev + 8 * 40);
+    PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(st));   // buf is on the stack
+    PLK_HIP(hipFree(dev));
+    ctx->coset_factors[key] = table;
+    *out = table;
     return PLK_OK;
 }
 
@@ -378,7 +436,9 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
         PLK_HIP(hipMalloc(&ctx->ntt_tmp[1], n * 32));
         ctx->ntt_tmp_cap = n;
     }
-    if (coset_gen && !inverse) PLK_TRY(scale_powers(ctx, st, data, n, host::el_load(coset_gen), host::one(host::FR)));
+    const uint32_t* factors = nullptr;
+    if (coset_gen && big) PLK_TRY(coset_factors(ctx, st, log_n, inverse, coset_gen, &factors));
+    if (coset_gen && !big && !inverse) PLK_TRY(scale_powers(ctx, st, data, n, host::el_load(coset_gen), host::one(host::FR)));
     NttScale ninv;
     memset(&ninv, 0, sizeof(ninv));
     if (inverse) {
@@ -406,13 +466,16 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
                 a.q[a.nsub++] = q;
                 left -= q;
             }
-            hipLaunchKernelGGL(k_ntt_pass8, dim3((uint32_t)(n / NTT8_TILE)), dim3(NTT8_THREADS), 0, st, src, dst, W, a, ninv);
+            const dim3 grid((uint32_t)(n / NTT8_TILE)), block(NTT8_THREADS);
+            if (factors && p == 0 && !inverse) hipLaunchKernelGGL((k_ntt_pass8<true, false>), grid, block, 0, st, src, dst, W, a, ninv, factors, nullptr);
+            else if (factors && last && inverse) hipLaunchKernelGGL((k_ntt_pass8<false, true>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, factors);
+            else hipLaunchKernelGGL((k_ntt_pass8<false, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, nullptr);
         }
         src = dst;
     }
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
-    if (coset_gen && inverse) {
+    if (coset_gen && inverse && !big) {
         const host::el gi = host::inv(host::FR, host::el_load(coset_gen));
         PLK_TRY(scale_powers(ctx, st, data, n, gi, host::one(host::FR)));
     }

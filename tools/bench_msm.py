@@ -55,6 +55,12 @@ if args.ntt:
     w = (time.perf_counter() - t0) / args.reps
     ms, cnt = ctx.profile_get("ntt")
     res.update(ntt_wall_ms=round(w * 1e3, 3), ntt_kernel_ms=round(ms / max(cnt, 1), 4), ntt_GBps=round(64 * n / (ms / max(cnt, 1) * 1e-3) / 1e9, 1))
-    t0 = time.perf_counter(); ctx.ntt_dev(d, args.log_n, coset=g5); ctx.ntt_dev(d, args.log_n, inverse=True, coset=g5)
-    res["coset_roundtrip_wall_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    ctx.ntt_dev(d, args.log_n, coset=g5); ctx.ntt_dev(d, args.log_n, inverse=True, coset=g5)   # builds the coset factor tables
+    for label, inv in (("coset_fwd", False), ("coset_inv", True)):
+        ctx.profile_reset()
+        for _ in range(args.reps):
+            ctx.ntt_dev(d, args.log_n, inverse=inv, coset=g5)
+        ms, cnt = ctx.profile_get("ntt")
+        res[label + "_kernel_ms"] = round(ms / max(cnt, 1), 4)
+        res[label + "_GBps"] = round(64 * n / (ms / max(cnt, 1) * 1e-3) / 1e9, 1)
 print(json.dumps(res))
