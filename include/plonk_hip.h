@@ -83,6 +83,16 @@ int32_t plk_ntt_dev(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t invers
 /* the same without waiting: the transform is ordered before every later call on this context (plk_sync or any call that returns data waits) */
 int32_t plk_ntt_dev_enqueue(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen);
 
+/* ---- building blocks of the multi-GPU (four-step) NTT: N = G * M points over G <= 8 devices, one all-to-all per transform
+ * (plonk_amd/dist_ntt.py drives them).  The reference has no counterpart: its transforms are single ark-poly fft / ifft calls
+ * (src/poly_utils.rs:27-28, src/prover.rs:232-237); these split one such transform across devices.
+ * plk_scale_powers_dev:  data[i] *= base * ratio^i, i < n  (the w_N^(g k2) twiddles between the two steps, coset factors).
+ * plk_ntt_cross_dev:     data is a [2^log_g][cols] array; every column is replaced by its 2^log_g-point transform
+ *                        (row k1 <- sum_g w_G^(+-g k1) row g; no 1/G factor in either direction), log_g <= 3.
+ * Both are enqueued on the context's stream like plk_ntt_dev_enqueue. */
+int32_t plk_scale_powers_dev(plk_ctx* ctx, void* data_dev, uint64_t n, const uint64_t base[4], const uint64_t ratio[4]);
+int32_t plk_ntt_cross_dev(plk_ctx* ctx, void* data_dev, uint32_t log_g, uint64_t cols, int32_t inverse);
+
 /* ---- interpolation helpers (src/poly_utils.rs:7-11 and :14-31).  sigma has sigma_len <= 2^log_n4 entries and is
  * padded with the identity; outputs are 2^log_n4 coefficients each (the caller strips trailing zeros, as
  * DensePolynomial::from_coefficients_vec does). */

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "../../include/plonk_hip.h"
@@ -133,6 +134,19 @@ int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes);
 #define PLK_SIDE_PRIO() __builtin_amdgcn_s_setprio(PLK_SIDE_PRIO_LEVEL)
 
 // ---- device helpers ----------------------------------------------------------------------------
+// f(integral_constant<0>) ... f(integral_constant<N-1>): a loop the compiler cannot leave rolled.  Loops whose body contains
+// several inlined modular products are sometimes kept as loops despite "#pragma unroll", and then a register array indexed by
+// the loop variable moves to scratch memory.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
 __device__ __forceinline__ void load8(const uint32_t* p, uint32_t* w) {
     const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;

@@ -296,34 +296,92 @@ __global__ void __launch_bounds__(256) k_ntt_twiddles(uint32_t* __restrict__ W, 
         if ((i >> k) & 1) w = mul<FrP>(w, mul<FrP>(ld_fe(pow2 + 8 * k), to_rp));
     st_fe<FrP>(W + 8ull * i, w);
 }
-// data[i] *= base * g^i.  pow2[k] = g^(2^k), base: x*2^256 words.  Each thread walks 8 consecutive elements.
-__global__ void __launch_bounds__(256) k_scale_powers(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict__ pow2, const uint32_t* __restrict__ base) {
+// g^(2^k) for k < 40 and a base factor, x*2^256 words; passed by value so that no staging buffer or wait is needed
+struct PowerArgs {
+    uint32_t pow2[40][8];
+    uint32_t base[8];
+};
+__device__ __forceinline__ fe power_at(const PowerArgs& a, uint64_t i0) {
+    const fe to_rp = fe_const(FrP::TO_RP);
+    fe cur = mul<FrP>(unpack(a.base), to_rp);
+    for (int k = 0; k < 40; ++k)
+        if ((i0 >> k) & 1) cur = mul<FrP>(cur, mul<FrP>(unpack(a.pow2[k]), to_rp));
+    return cur;   // base * g^i0 in the 2^261 form
+}
+// data[i] *= base * g^i.  Each thread walks 8 consecutive elements.
+__global__ void __launch_bounds__(256) k_scale_powers(uint32_t* __restrict__ data, uint64_t n, PowerArgs a) {
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i0 >= n) return;
-    const fe to_rp = fe_const(FrP::TO_RP);
-    fe cur = mul<FrP>(ld_fe(base), to_rp);
-    for (int k = 0; k < 40; ++k)
-        if ((i0 >> k) & 1) cur = mul<FrP>(cur, mul<FrP>(ld_fe(pow2 + 8 * k), to_rp));
-    const fe g = mul<FrP>(ld_fe(pow2), to_rp);
+    fe cur = power_at(a, i0);
+    const fe g = mul<FrP>(unpack(a.pow2[0]), fe_const(FrP::TO_RP));
     for (int k = 0; k < 8 && i0 + k < n; ++k) {
         st_fe<FrP>(data + 8 * (i0 + k), mul<FrP>(ld_fe(data + 8 * (i0 + k)), cur));
         cur = mul<FrP>(cur, g);
     }
 }
-
-// out[i] = base * g^i in the 2^261 form (a multiplication operand that keeps the other factor's form).  Inputs as in k_scale_powers.
-__global__ void __launch_bounds__(256) k_power_table(uint32_t* __restrict__ out, uint64_t n, const uint32_t* __restrict__ pow2, const uint32_t* __restrict__ base) {
+// out[i] = base * g^i in the 2^261 form (a multiplication operand that keeps the other factor's form)
+__global__ void __launch_bounds__(256) k_power_table(uint32_t* __restrict__ out, uint64_t n, PowerArgs a) {
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i0 >= n) return;
-    const fe to_rp = fe_const(FrP::TO_RP);
-    fe cur = mul<FrP>(ld_fe(base), to_rp);
-    for (int k = 0; k < 40; ++k)
-        if ((i0 >> k) & 1) cur = mul<FrP>(cur, mul<FrP>(ld_fe(pow2 + 8 * k), to_rp));
-    const fe g = mul<FrP>(ld_fe(pow2), to_rp);
+    fe cur = power_at(a, i0);
+    const fe g = mul<FrP>(unpack(a.pow2[0]), fe_const(FrP::TO_RP));
     for (int k = 0; k < 8 && i0 + k < n; ++k) {
         st_fe<FrP>(out + 8 * (i0 + k), cur);
         cur = mul<FrP>(cur, g);
     }
+}
+static PowerArgs power_args(const host::el& g, const host::el& base) {
+    PowerArgs a;
+    host::el p = g;
+    for (int k = 0; k < 40; ++k) { memcpy(a.pow2[k], p.v, 32); p = host::mul(host::FR, p, p); }
+    memcpy(a.base, base.v, 32);
+    return a;
+}
+
+// G-point transforms down the columns of a [G][cols] array, G = 2^LG <= 8, in place: row k1 receives
+// sum_g w_G^(+-g k1) row g.  One thread per column, all G values in registers.  No scaling in either direction.
+// Values are canonical on the way in and out.
+template <int LG, int D>
+__device__ __forceinline__ void cross_stage(fe* x, const uint32_t* __restrict__ W, int inverse) {
+#pragma unroll
+    for (int low = 0; low < (1 << D); ++low) {
+        const fe w = twiddle_operand(W, (uint32_t)low << (LG - D - 1), LG, inverse);
+#pragma unroll
+        for (int hi = 0; hi < (1 << (LG - D - 1)); ++hi) {
+            const int m0 = (hi << (D + 1)) | low, m1 = m0 | (1 << D);
+            const fe u = x[m0];
+            const fe t = mul<FrP>(x[m1], w);
+            x[m0] = add(u, t);
+            x[m1] = sub2<FrP>(u, t);
+        }
+    }
+}
+template <int LG>
+__global__ void __launch_bounds__(256) k_ntt_cross(uint32_t* __restrict__ data, uint64_t cols, const uint32_t* __restrict__ W /* w_G^i, i < G/2 */, int inverse) {
+    constexpr int G = 1 << LG;
+    const uint64_t col = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    fe x[G];
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+        int row = 0;
+#pragma unroll
+        for (int b = 0; b < LG; ++b) row |= ((m >> b) & 1) << (LG - 1 - b);
+        x[m] = ld_fe(data + 8ull * ((uint64_t)row * cols + col));
+    }
+    cross_stage<LG, 0>(x, W, inverse);
+    if constexpr (LG > 1) cross_stage<LG, 1>(x, W, inverse);
+    if constexpr (LG > 2) {   // limbs grow by 2^30 per stage: bring them back below 2^29 after two stages
+#pragma unroll
+        for (int m = 0; m < G; ++m) norm(x[m]);
+        cross_stage<LG, 2>(x, W, inverse);
+    }
+    const fe one = fe_const(FrP::ONE);
+    static_for<G>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        norm(x[m]);
+        st_fe<FrP>(data + 8ull * ((uint64_t)m * cols + col), mul<FrP>(x[m], one));
+    });
 }
 
 static host::el root_of_unity(uint32_t log_n) {
@@ -362,18 +420,8 @@ void ntt_release(plk_ctx* ctx) {
 }
 
 static int32_t scale_powers(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint64_t n, const host::el& g, const host::el& base) {
-    uint64_t buf[41 * 4];
-    host::el p = g;
-    for (int k = 0; k < 40; ++k) { memcpy(buf + 4 * k, p.v, 32); p = host::mul(host::FR, p, p); }
-    memcpy(buf + 160, base.v, 32);
-    uint32_t* dev = nullptr;
-    PLK_HIP(hipMalloc(&dev, sizeof(buf)));
-    PLK_HIP(hipMemcpyAsync(dev, buf, sizeof(buf), hipMemcpyHostToDevice, st));
-    PLK_HIP(hipStreamSynchronize(st));   // buf is on the stack
-    hipLaunchKernelGGL(k_scale_powers, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, st, data, n, dev, dev + 8 * 40);
+    hipLaunchKernelGGL(k_scale_powers, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, st, data, n, power_args(g, base));
     PLK_HIP(hipGetLastError());
-    PLK_HIP(hipStreamSynchronize(st));
-    PLK_HIP(hipFree(dev));
     return PLK_OK;
 }
 
@@ -390,18 +438,10 @@ static int32_t coset_factors(plk_ctx* ctx, hipStream_t st, uint32_t log_n, bool 
         g = host::inv(host::FR, g);
         base = host::inv(host::FR, host::from_u64(host::FR, n));
     }
-    uint64_t buf[41 * 4];
-    host::el p = g;
-    for (int k = 0; k < 40; ++k) { memcpy(buf + 4 * k, p.v, 32); p = host::mul(host::FR, p, p); }
-    memcpy(buf + 160, base.v, 32);
-    uint32_t *dev = nullptr, *table = nullptr;
-    PLK_HIP(hipMalloc(&dev, sizeof(buf)));
-    if (hipMalloc(&table, n * 32) != hipSuccess) { hipFree(dev); ctx->err = "out of device memory for the coset factors"; return PLK_ERR_ALLOC; }
-    PLK_HIP(hipMemcpyAsync(dev, buf, sizeof(buf), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_power_table, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, table, n, dev, dev + 8 * 40);
+    uint32_t* table = nullptr;
+    if (hipMalloc(&table, n * 32) != hipSuccess) { ctx->err = "out of device memory for the coset factors"; return PLK_ERR_ALLOC; }
+    hipLaunchKernelGGL(k_power_table, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, table, n, power_args(g, base));
     PLK_HIP(hipGetLastError());
-    PLK_HIP(hipStreamSynchronize(st));   // buf is on the stack
-    PLK_HIP(hipFree(dev));
     ctx->coset_factors[key] = table;
     *out = table;
     return PLK_OK;
@@ -508,4 +548,32 @@ extern "C" int32_t plk_ntt(plk_ctx* ctx, uint64_t* data_host, uint32_t log_n, in
     if (rc == PLK_OK && hipMemcpy(data_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
     hipFree(d);
     return rc;
+}
+
+extern "C" int32_t plk_scale_powers_dev(plk_ctx* ctx, void* data_dev, uint64_t n, const uint64_t base[4], const uint64_t ratio[4]) {
+    if (!ctx || !base || !ratio || (n && !data_dev)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return PLK_OK;
+    prof_begin(ctx, ctx->stream, "pointwise");
+    const int32_t rc = scale_powers(ctx, ctx->stream, (uint32_t*)data_dev, n, host::el_load(ratio), host::el_load(base));
+    prof_end(ctx, ctx->stream);
+    return rc;
+}
+extern "C" int32_t plk_ntt_cross_dev(plk_ctx* ctx, void* data_dev, uint32_t log_g, uint64_t cols, int32_t inverse) {
+    if (!ctx || !data_dev || log_g > 3) return PLK_ERR_INVALID_ARG;   // at most 8 row blocks (GPUs of one node)
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (log_g == 0 || cols == 0) return PLK_OK;
+    const uint32_t* W;
+    PLK_TRY(ntt_twiddles(ctx, log_g, &W));
+    const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
+    uint32_t* d = (uint32_t*)data_dev;
+    prof_begin(ctx, ctx->stream, "ntt");
+    switch (log_g) {
+        case 1: hipLaunchKernelGGL(k_ntt_cross<1>, grid, block, 0, ctx->stream, d, cols, W, inverse ? 1 : 0); break;
+        case 2: hipLaunchKernelGGL(k_ntt_cross<2>, grid, block, 0, ctx->stream, d, cols, W, inverse ? 1 : 0); break;
+        default: hipLaunchKernelGGL(k_ntt_cross<3>, grid, block, 0, ctx->stream, d, cols, W, inverse ? 1 : 0); break;
+    }
+    prof_end(ctx, ctx->stream);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
 }

@@ -22,6 +22,7 @@ EXPORTS = [
     "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync", "plk_copy_dev",
     "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_read",
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
+    "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
     "plk_grand_product", "plk_grand_product_dev", "plk_quotient", "plk_quotient_dev", "plk_poly_eval", "plk_poly_eval_dev",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
@@ -44,6 +45,15 @@ def load_library():
     """Loads libplonk_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
     global _lib
     if _lib is None:
+        # PyTorch wheels carry their own HIP/HSA runtime under the same sonames as /opt/rocm's.  A process can hold only one
+        # (the second fails to open the device: "No HIP GPUs are available"), and the dynamic linker shares a copy only when
+        # torch's is the one loaded first.  Callers that use torch beside this library (torch.distributed collectives on
+        # device buffers) therefore need torch imported before libplonk_hip.so; PLK_NO_TORCH=1 skips this.
+        if not os.environ.get("PLK_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C plonk_amd/csrc` (no CPU fallback exists)")
         _lib = C.CDLL(LIB_PATH)
@@ -172,6 +182,16 @@ class Context:
     def ntt_dev(self, dptr, log_n, inverse=False, coset=None):
         self._ck(self.lib.plk_ntt_dev(self.h, _vp(dptr), C.c_uint32(log_n), C.c_int32(int(inverse)),
                                       _ptr(_fr(coset, (4,))) if coset is not None else None))
+
+    def ntt_dev_enqueue(self, dptr, log_n, inverse=False, coset=None):
+        self._ck(self.lib.plk_ntt_dev_enqueue(self.h, _vp(dptr), C.c_uint32(log_n), C.c_int32(int(inverse)),
+                                              _ptr(_fr(coset, (4,))) if coset is not None else None))
+
+    def scale_powers_dev(self, dptr, n, base, ratio):
+        self._ck(self.lib.plk_scale_powers_dev(self.h, _vp(dptr), C.c_uint64(n), _ptr(_fr(base, (4,))), _ptr(_fr(ratio, (4,)))))
+
+    def ntt_cross_dev(self, dptr, log_g, cols, inverse=False):
+        self._ck(self.lib.plk_ntt_cross_dev(self.h, _vp(dptr), C.c_uint32(log_g), C.c_uint64(cols), C.c_int32(int(inverse))))
 
     def interpolate_selector(self, values):
         v = _fr(values)
