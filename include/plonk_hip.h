@@ -120,6 +120,22 @@ int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void*
                          const void* q_mul_vals, const void* z_vals, const void* sigma, uint32_t log_n,
                          const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev, uint64_t* t_len);
 
+/* ---- quotient on the extended coset.  No counterpart in the reference, which evaluates its constraints on H only and therefore
+ * always obtains t = 0 (src/circuit.rs:442-489); this is the same constraint system taken as polynomial identities, the form a
+ * prover with a non-trivial quotient needs.  With a, b, c, q_add, q_mul, z the degree < n interpolants of the given values on H,
+ * ID_k the interpolant of the labels 3i + k (src/prover.rs:205) and SG_k of sigma(3i + k) (src/circuit.rs:356-368), k < 3:
+ *   num(X) = q_add (a + b - c) + q_mul (a b - c)                                     (gate, src/circuit.rs:446-453)
+ *          + alpha [ z(X) prod_k (w_k + beta ID_k + gamma) - z(wX) prod_k (w_k + beta SG_k + gamma) ]   (src/circuit.rs:343-379)
+ *   t(X)   = num(X) / (X^n - 1)
+ * evaluated on the coset g H_4n (g = coset_gen, NULL = 5) and interpolated back: t_out receives 4n coefficients (the last n + 3
+ * are zero).  Returns PLK_ERR_NOT_DIVISIBLE when num is not a multiple of X^n - 1 (t_out then holds the coset interpolant). */
+int32_t plk_quotient_coset(plk_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* q_add_vals,
+                           const uint64_t* q_mul_vals, const uint64_t* z_vals, const uint64_t* sigma, uint32_t log_n, const uint64_t beta[4],
+                           const uint64_t gamma[4], const uint64_t alpha[4], const uint64_t* coset_gen, uint64_t* t_out_host);
+int32_t plk_quotient_coset_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                               const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                               const uint64_t alpha[4], const uint64_t* coset_gen, void* t_out_dev);
+
 /* ---- DensePolynomial::evaluate (src/prover.rs:266-274) */
 int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t x[4], uint64_t out[4]);
 int32_t plk_poly_eval_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], uint64_t out[4]);

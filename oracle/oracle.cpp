@@ -491,6 +491,50 @@ int orc_quotient(const uint64_t* a, const uint64_t* b, const uint64_t* c, const 
     Fr be, ga; memcpy(be.v, beta, 32); memcpy(ga.v, gamma, 32); std::vector<Fr> t;
     return quotient((const Fr*)a, (const Fr*)b, (const Fr*)c, (const Fr*)qa, (const Fr*)qm, (const Fr*)zv, sigma, log_n, be, ga, t);
 }
+// Quotient of the reference's constraint system on polynomials, as plk_quotient_coset defines it (no counterpart in the reference,
+// which never leaves H: src/circuit.rs:442-489).  With a, b, c, q_add, q_mul, z the degree < n interpolants of the column values,
+// ID_k of the labels 3i + k and SG_k of sigma(3i + k) (the labels of src/prover.rs:205 and src/circuit.rs:356-368):
+//   num(X) = q_add (a + b - c) + q_mul (a b - c) + alpha [ z(X) prod_k (w_k + beta ID_k + gamma) - z(wX) prod_k (w_k + beta SG_k + gamma) ]
+//   t(X)   = num(X) / (X^n - 1),  4n coefficients out; returns 1 when the remainder is not zero.
+// Checked here WITHOUT a coset: values on the plain domain of size 4n, back to coefficients, schoolbook division by X^n - 1.
+int orc_quotient_coset(const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* qa, const uint64_t* qm, const uint64_t* zv,
+                       const uint64_t* sigma, int log_n, const uint64_t* beta, const uint64_t* gamma, const uint64_t* alpha, uint64_t* t_out) {
+    const size_t n = (size_t)1 << log_n, n4 = 4 * n;
+    Fr be, ga, al; memcpy(be.v, beta, 32); memcpy(ga.v, gamma, 32); memcpy(al.v, alpha, 32);
+    auto extend = [&](std::vector<Fr> vals) {   // values on H -> values on the domain of size 4n
+        ntt_inplace(vals.data(), log_n, true, nullptr);
+        vals.resize(n4, Fr::zero());
+        ntt_inplace(vals.data(), log_n + 2, false, nullptr);
+        return vals;
+    };
+    auto column = [&](const uint64_t* src) { std::vector<Fr> v(n); memcpy(v.data(), src, n * 32); return extend(v); };
+    std::vector<Fr> A = column(a), B = column(b), Cc = column(c), QA = column(qa), QM = column(qm), Z = column(zv);
+    std::vector<Fr> ID[3], SG[3];
+    for (int k = 0; k < 3; ++k) {
+        std::vector<Fr> id(n), sg(n);
+        for (size_t i = 0; i < n; ++i) { id[i] = from_u64<FrTag>(3 * i + k); sg[i] = from_u64<FrTag>(sigma[3 * i + k]); }
+        ID[k] = extend(id); SG[k] = extend(sg);
+    }
+    std::vector<Fr> num(n4);
+    for (size_t i = 0; i < n4; ++i) {
+        const Fr* w[3] = {&A[i], &B[i], &Cc[i]};
+        Fr gate = add(mul(QA[i], sub(add(A[i], B[i]), Cc[i])), mul(QM[i], sub(mul(A[i], B[i]), Cc[i])));
+        Fr l = Z[i], r = Z[(i + 4) % n4];                     // z(w x): w = w_{4n}^4
+        for (int k = 0; k < 3; ++k) {
+            l = mul(l, add(add(*w[k], mul(be, ID[k][i])), ga));
+            r = mul(r, add(add(*w[k], mul(be, SG[k][i])), ga));
+        }
+        num[i] = add(gate, mul(al, sub(l, r)));
+    }
+    ntt_inplace(num.data(), log_n + 2, true, nullptr);          // degree <= 4n - 4: exact
+    std::vector<Fr> q(n4, Fr::zero());
+    for (size_t i = n4; i-- > n;) q[i - n] = add(num[i], q[i]);   // f = q (X^n - 1) + r
+    int bad = 0;
+    for (size_t i = 0; i < n; ++i) if (!add(num[i], q[i]).is_zero()) bad = 1;
+    memcpy(t_out, q.data(), n4 * 32);
+    return bad;
+}
+
 void orc_kzg_commit(const uint64_t* g, uint64_t ng, const uint64_t* gg, const uint64_t* coeffs, uint64_t len, const uint64_t* blind, uint64_t* out, int32_t* oinf) {
     Srs s{g, ng, gg}; store_aff(kzg_commit(s, (const Fr*)coeffs, len, (const Fr*)blind), out, oinf);
 }

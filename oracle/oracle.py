@@ -191,6 +191,15 @@ def quotient(a, b, c, qa, qm, zv, sigma, beta, gamma) -> int:
                               _p(_u64(beta)), _p(_u64(gamma)))
 
 
+def quotient_coset(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha):
+    """(status, 4n coefficients of t) of the extended quotient, computed without a coset (see orc_quotient_coset)."""
+    a = _u64(a).reshape(-1, 4); n = len(a); log_n = (n - 1).bit_length()
+    out = np.zeros((4 * n, 4), dtype=np.uint64)
+    rc = lib().orc_quotient_coset(_p(a), _p(_u64(b)), _p(_u64(c)), _p(_u64(qa)), _p(_u64(qm)), _p(_u64(zv)), _p(_u64(sigma)), log_n,
+                                  _p(_u64(beta)), _p(_u64(gamma)), _p(_u64(alpha)), _p(out))
+    return rc, out
+
+
 def kzg_commit(g, gg, coeffs, blind):
     g = _u64(g).reshape(-1, 8); c = _u64(coeffs).reshape(-1, 4)
     out = np.empty(8, dtype=np.uint64); oinf = C.c_int32(0)

@@ -329,6 +329,68 @@ __global__ void __launch_bounds__(256) k_perm_values(const uint64_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------ quotient on the extended coset
+// Labels of the copy constraint as field elements (x*2^256): idx[i] = i, sg_k[i] = sigma(3i + k)   (src/prover.rs:205, src/circuit.rs:356-368)
+__global__ void __launch_bounds__(256) k_coset_labels(const uint64_t* __restrict__ sigma, uint64_t n, uint32_t* __restrict__ idx, uint32_t* __restrict__ sg0,
+                                                      uint32_t* __restrict__ sg1, uint32_t* __restrict__ sg2, uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const fe r2 = fe_const(FrP::R2), to_r = fe_const(FrP::TO_R);
+    uint32_t* dst[4] = {idx, sg0, sg1, sg2};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint64_t v = k == 0 ? i : sigma[3 * i + (k - 1)];
+        if (v >= 3 * n) { atomicOr(flag, 2u); v = 0; }
+        fe j = fe_zero();
+        j.v[0] = (uint32_t)v;                                          // < 2^29
+        st_fe<FrP>(dst[k] + 8 * i, mul<FrP>(mul<FrP>(j, r2), to_r));   // j * 2^261, then j * 2^256
+    }
+}
+struct CosetQuotientArgs {
+    W8 beta, gamma, alpha;
+    W8 zh_inv[4];   // 1 / (x^n - 1) at coset point i depends on i mod 4 only: x^n = g^n w_4^i
+};
+// One coset point per thread: all ten polynomials are read once (z twice: at x and at w x, four slots further on), one value is written.
+//   out = [ q_add (a + b - c) + q_mul (a b - c) + alpha ( z prod_k (w_k + beta (3 I + k) + gamma) - z' prod_k (w_k + beta SG_k + gamma) ) ] / (x^n - 1)
+__global__ void __launch_bounds__(256) k_quotient_coset(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
+                                                        const uint32_t* __restrict__ qa, const uint32_t* __restrict__ qm, const uint32_t* __restrict__ z,
+                                                        const uint32_t* __restrict__ idx, const uint32_t* __restrict__ sg0, const uint32_t* __restrict__ sg1,
+                                                        const uint32_t* __restrict__ sg2, uint64_t n4, CosetQuotientArgs args, uint32_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const fe beta1 = to_rp(fe_of(args.beta));                          // beta * 2^261
+    const fe gamma1 = to_rp(fe_of(args.gamma)), alpha1 = to_rp(fe_of(args.alpha));
+    // data are x*2^256 and to_rp(x) = x*2^261; beta in the form beta * 2^266 turns x*2^256 into beta x * 2^261 with one product
+    const fe beta_up = to_rp(beta1);
+    const fe w[3] = {ld_fe(a + 8 * i), ld_fe(b + 8 * i), ld_fe(c + 8 * i)};
+    const fe w1[3] = {to_rp(w[0]), to_rp(w[1]), to_rp(w[2])};
+    // gate
+    fe s = add(w[0], w[1]);
+    s = sub2<FrP>(s, w[2]); norm(s);                                   // a + b - c, bound 4
+    fe m = sub2<FrP>(mul<FrP>(w1[0], w[1]), w[2]); norm(m);            // a b - c, bound 4
+    const fe gate = add(mul<FrP>(to_rp(ld_fe(qa + 8 * i)), s), mul<FrP>(to_rp(ld_fe(qm + 8 * i)), m));   // bound 4, limbs < 2^30
+    // copy constraint: terms in the 2^261 form so that the running products keep z's 2^256 form
+    const fe bi = mul<FrP>(beta_up, ld_fe(idx + 8 * i));               // beta I * 2^261, bound 2
+    fe bi3 = add(add(bi, bi), bi);                                     // bound 6
+    const uint32_t* sg[3] = {sg0, sg1, sg2};
+    fe l = ld_fe(z + 8 * i), r = ld_fe(z + 8 * ((i + 4) & (n4 - 1)));
+    fe kb = fe_zero();                                                 // k * beta * 2^261, bound k
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        fe tl = add(add(add(w1[k], bi3), kb), gamma1);                 // bound <= 2 + 6 + 2 + 2
+        norm(tl);
+        fe tr = add(add(w1[k], mul<FrP>(beta_up, ld_fe(sg[k] + 8 * i))), gamma1);   // bound <= 6
+        norm(tr);
+        l = mul<FrP>(l, tl);
+        r = mul<FrP>(r, tr);
+        kb = add(kb, beta1);
+    }
+    fe d = sub2<FrP>(l, r); norm(d);                                   // bound 4
+    fe v = add(gate, mul<FrP>(alpha1, d));                             // bound 6
+    norm(v);
+    st_fe<FrP>(out + 8 * i, mul<FrP>(to_rp(fe_of(args.zh_inv[i & 3])), v));
+}
+
 }  // namespace plk
 
 using namespace plk;
@@ -524,4 +586,88 @@ extern "C" int32_t plk_interpolate_selector(plk_ctx* ctx, const uint64_t* values
     memset(coeffs_out_host + 4 * len, 0, (n - len) * 32);
     *log_n_out = log_n;
     return plk_ntt(ctx, coeffs_out_host, log_n, 1, nullptr);
+}
+
+// Extended-coset quotient: see include/plonk_hip.h.  Ten polynomials go from values on H to values on the coset g H_4n
+// (inverse NTT of n points, zero padding, coset NTT of 4n points), one pointwise kernel, one inverse coset NTT.
+extern "C" int32_t plk_quotient_coset_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                                          const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                                          const uint64_t alpha[4], const uint64_t* coset_gen, void* t_out_dev) {
+    if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !beta || !gamma || !alpha || !t_out_dev || log_n > 25)
+        return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n, n4 = 4 * n;
+    hipStream_t st = ctx->stream;
+    host::el g = coset_gen ? host::el_load(coset_gen) : host::from_u64(host::FR, 5);
+    // 1 / (g^n w_4^i - 1), i < 4
+    host::el gn = g;
+    for (uint32_t k = 0; k < log_n; ++k) gn = host::mul(host::FR, gn, gn);
+    static const uint64_t ROOT28[4] = {0x636e735580d13d9cULL, 0xa22bf3742445ffd6ULL, 0x56452ac01eb203d8ULL, 0x1860ef942963f9e7ULL};
+    host::el w4 = host::el_load(ROOT28);
+    for (int k = 2; k < 28; ++k) w4 = host::mul(host::FR, w4, w4);
+    CosetQuotientArgs args;
+    args.beta = w8_of(beta); args.gamma = w8_of(gamma); args.alpha = w8_of(alpha);
+    host::el x = gn;
+    for (int i = 0; i < 4; ++i) {
+        const host::el d = host::sub(host::FR, x, host::one(host::FR));
+        if (host::is_zero(d)) { ctx->err = "the coset meets the domain: Z_H vanishes on it"; return PLK_ERR_INVERSE_OF_ZERO; }
+        args.zh_inv[i] = w8_of(host::inv(host::FR, d));
+        x = host::mul(host::FR, x, w4);
+    }
+    uint32_t* work = nullptr;
+    if (hipMalloc(&work, 10 * n4 * 32) != hipSuccess) { ctx->err = "out of device memory for the coset evaluations"; return PLK_ERR_ALLOC; }
+    uint32_t* p[10];
+    for (int k = 0; k < 10; ++k) p[k] = work + (size_t)k * n4 * 8;
+    const void* cols[6] = {a, b, c, q_add_vals, q_mul_vals, z_vals};
+    int32_t rc = PLK_OK;
+    auto fail = [&](int32_t code) { hipStreamSynchronize(st); hipFree(work); return code; };
+    if (hipMemsetAsync(ctx->flag_dev, 0, 4, st) != hipSuccess) return fail(PLK_ERR_HIP);
+    for (int k = 0; k < 6; ++k)
+        if (hipMemcpyAsync(p[k], cols[k], n * 32, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(PLK_ERR_HIP);
+    prof_begin(ctx, st, "pointwise");
+    hipLaunchKernelGGL(k_coset_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint64_t*)sigma, n, p[6], p[7], p[8], p[9], ctx->flag_dev);
+    prof_end(ctx, st);
+    const uint64_t gen_limbs[4] = {g.v[0], g.v[1], g.v[2], g.v[3]};
+    for (int k = 0; k < 10 && rc == PLK_OK; ++k) {
+        rc = ntt_run(ctx, st, p[k], log_n, true, nullptr);
+        if (rc == PLK_OK && hipMemsetAsync(p[k] + n * 8, 0, 3 * n * 32, st) != hipSuccess) rc = PLK_ERR_HIP;
+        if (rc == PLK_OK) rc = ntt_run(ctx, st, p[k], log_n + 2, false, gen_limbs);
+    }
+    if (rc != PLK_OK) return fail(rc);
+    uint32_t* t = (uint32_t*)t_out_dev;
+    prof_begin(ctx, st, "pointwise");
+    hipLaunchKernelGGL(k_quotient_coset, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], n4, args, t);
+    prof_end(ctx, st);
+    if (hipGetLastError() != hipSuccess) return fail(PLK_ERR_HIP);
+    rc = ntt_run(ctx, st, t, log_n + 2, true, gen_limbs);
+    if (rc != PLK_OK) return fail(rc);
+    // the numerator has degree <= 4n - 4, so it is a multiple of X^n - 1 exactly when coefficients 3n - 3 .. 4n - 1 of t vanish
+    const uint64_t first = 3 * n >= 3 ? 3 * n - 3 : 0;
+    hipLaunchKernelGGL(k_any_nonzero, dim3(64), dim3(256), 0, st, t + first * 8, (n4 - first) * 8, ctx->flag_dev);
+    uint32_t flag = 0;
+    rc = read_flag(ctx, &flag);
+    hipFree(work);
+    prof_collect(ctx, false);
+    PLK_TRY(rc);
+    if (flag & 2u) { ctx->err = "sigma entry out of range"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
+    if (flag & 1u) { ctx->err = "t(X) not divisible by Z_H(X)"; return PLK_ERR_NOT_DIVISIBLE; }
+    return PLK_OK;
+}
+extern "C" int32_t plk_quotient_coset(plk_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* q_add_vals,
+                                      const uint64_t* q_mul_vals, const uint64_t* z_vals, const uint64_t* sigma, uint32_t log_n, const uint64_t beta[4],
+                                      const uint64_t gamma[4], const uint64_t alpha[4], const uint64_t* coset_gen, uint64_t* t_out_host) {
+    if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !t_out_host || log_n > 25) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n;
+    const uint64_t* src[6] = {a, b, c, q_add_vals, q_mul_vals, z_vals};
+    void* d[6]; void *s, *t;
+    for (int i = 0; i < 6; ++i) { PLK_HIP(hipMalloc(&d[i], n * 32)); PLK_HIP(hipMemcpy(d[i], src[i], n * 32, hipMemcpyHostToDevice)); }
+    PLK_HIP(hipMalloc(&s, 3 * n * 8)); PLK_HIP(hipMemcpy(s, sigma, 3 * n * 8, hipMemcpyHostToDevice));
+    PLK_HIP(hipMalloc(&t, 4 * n * 32));
+    int32_t rc = plk_quotient_coset_dev(ctx, d[0], d[1], d[2], d[3], d[4], d[5], s, log_n, beta, gamma, alpha, coset_gen, t);
+    // the coefficients are returned in both cases: a caller may want to look at a quotient that does not divide
+    if ((rc == PLK_OK || rc == PLK_ERR_NOT_DIVISIBLE) && hipMemcpy(t_out_host, t, 4 * n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
+    for (int i = 0; i < 6; ++i) hipFree(d[i]);
+    hipFree(s); hipFree(t);
+    return rc;
 }

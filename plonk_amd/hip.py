@@ -24,7 +24,7 @@ EXPORTS = [
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
-    "plk_grand_product", "plk_grand_product_dev", "plk_quotient", "plk_quotient_dev", "plk_poly_eval", "plk_poly_eval_dev",
+    "plk_grand_product", "plk_grand_product_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
     "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
@@ -236,6 +236,20 @@ class Context:
         self._ck(self.lib.plk_quotient_dev(self.h, _vp(d_a), _vp(d_b), _vp(d_c), _vp(d_qa), _vp(d_qm), _vp(d_zv), _vp(d_sigma), C.c_uint32(log_n),
                                            _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))), _vp(d_t), C.byref(tlen)))
         return tlen.value
+
+    def quotient_coset(self, a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, coset=None):
+        """4n coefficients of the extended-coset quotient; raises PLK_ERR_NOT_DIVISIBLE for a witness that does not satisfy the constraints."""
+        a = _fr(a); n = len(a); log_n = (n - 1).bit_length()
+        out = np.empty((4 * n, 4), dtype=np.uint64)
+        self._ck(self.lib.plk_quotient_coset(self.h, _ptr(a), _ptr(_fr(b)), _ptr(_fr(c)), _ptr(_fr(qa)), _ptr(_fr(qm)), _ptr(_fr(zv)),
+                                             _ptr(np.ascontiguousarray(sigma, dtype=np.uint64)), C.c_uint32(log_n), _ptr(_fr(beta, (4,))),
+                                             _ptr(_fr(gamma, (4,))), _ptr(_fr(alpha, (4,))), _ptr(_fr(coset, (4,))) if coset is not None else None, _ptr(out)))
+        return out
+
+    def quotient_coset_dev(self, d_a, d_b, d_c, d_qa, d_qm, d_zv, d_sigma, log_n, beta, gamma, alpha, d_t, coset=None):
+        self._ck(self.lib.plk_quotient_coset_dev(self.h, _vp(d_a), _vp(d_b), _vp(d_c), _vp(d_qa), _vp(d_qm), _vp(d_zv), _vp(d_sigma), C.c_uint32(log_n),
+                                                 _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))), _ptr(_fr(alpha, (4,))),
+                                                 _ptr(_fr(coset, (4,))) if coset is not None else None, _vp(d_t)))
 
     def poly_eval(self, coeffs, x):
         c = _fr(coeffs); out = np.empty(4, dtype=np.uint64)

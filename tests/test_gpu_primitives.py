@@ -135,6 +135,28 @@ def test_grand_product_and_quotient(ctx, orc, log_n):
     assert orc.quotient(a, b, bad, qa, qm, zv, sigma, beta, gamma) == 1
 
 
+@pytest.mark.parametrize("log_n,coset", [(0, None), (1, None), (2, None), (3, 7), (5, None), (9, None), (12, 7)])
+def test_quotient_on_the_extended_coset(ctx, orc, log_n, coset):
+    """plk_quotient_coset against the oracle, which divides in coefficient form and never touches a coset."""
+    inp = _circuit(orc, log_n, 31 + log_n)
+    w = orc.fr_from_ints(inp["witness_flat"]); sigma = np.array(inp["sigma"], dtype=np.uint64)
+    beta, gamma, alpha = rand_fr(orc, 3, 78 + log_n)
+    zv, _ = orc.grand_product(w, sigma, beta, gamma)
+    a, b, c, qa, qm = (orc.fr_from_ints(col) for col in inp["cols"])
+    g = orc.fr_from_ints([coset])[0] if coset is not None else None
+    got = ctx.quotient_coset(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, coset=g)
+    rc, want = orc.quotient_coset(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha)
+    assert rc == 0 and np.array_equal(got, want)
+    if log_n >= 2:
+        assert got.any()                                   # unlike the reference's t, this quotient is not the zero polynomial
+        from plonk_amd.hip import PlonkHipError
+        bad = c.copy(); bad[1] = a[0]
+        with pytest.raises(PlonkHipError) as e:
+            ctx.quotient_coset(a, b, bad, qa, qm, zv, sigma, beta, gamma, alpha, coset=g)
+        assert e.value.status == "PLK_ERR_NOT_DIVISIBLE"
+        assert orc.quotient_coset(a, b, bad, qa, qm, zv, sigma, beta, gamma, alpha)[0] == 1
+
+
 def test_interpolate_permutation(ctx, orc):
     inp = _circuit(orc, 4, 5)
     log_n4 = inp["n4"].bit_length() - 1

@@ -130,3 +130,36 @@ def test_oracle_rejects_bad_witness(orc):
     assert orc.quotient(a, b, c, qa, qm, zv, sigma, beta, gamma) == 0
     c[2] = a[0]
     assert orc.quotient(a, b, c, qa, qm, zv, sigma, beta, gamma) == 1
+
+
+def test_oracle_extended_quotient_satisfies_its_identity(orc):
+    """orc.quotient_coset (the checker of plk_quotient_coset) against Python integers: t(x) (x^n - 1) = num(x) at a point off the domain."""
+    log_n = 3
+    variables, gates = pm.synthetic_circuit(log_n, 9)
+    inp = pm.prepare_inputs(variables, gates)
+    n, R = inp["n"], pm.R_MOD
+    rng = pm.SplitMix64(123)
+    beta, gamma, alpha, x = (rng.next_fr() for _ in range(4))
+    z_vals, _ = pm.build_grand_product(inp["witness_flat"], inp["sigma"], n, beta, gamma)
+    cols = [orc.fr_from_ints(c) for c in inp["cols"]]
+    f = lambda v: orc.fr_from_ints([v])[0]
+    rc, t = orc.quotient_coset(*cols, orc.fr_from_ints(z_vals[:n]), np.array(inp["sigma"], dtype=np.uint64), f(beta), f(gamma), f(alpha))
+    assert rc == 0
+    t = orc.fr_to_ints(t)
+    assert any(t[:3 * n - 3]) and not any(t[3 * n - 3:])
+    w = pow(5, (R - 1) // n, R)
+    horner = lambda cs, at: sum(c * pow(at, i, R) for i, c in enumerate(cs)) % R
+    interp = lambda vals: pm.ntt(list(vals), n, inverse=True)
+    a, b, c, qa, qm = (interp(col) for col in inp["cols"])
+    zc = interp(z_vals[:n])
+    A, B, Cc, QA, QM = (horner(p, x) for p in (a, b, c, qa, qm))
+    lhs, rhs = horner(zc, x), horner(zc, w * x % R)
+    for k, wv in enumerate((A, B, Cc)):
+        lhs = lhs * (wv + beta * horner(interp([3 * i + k for i in range(n)]), x) + gamma) % R
+        rhs = rhs * (wv + beta * horner(interp([inp["sigma"][3 * i + k] for i in range(n)]), x) + gamma) % R
+    num = (QA * (A + B - Cc) + QM * (A * B - Cc) + alpha * (lhs - rhs)) % R
+    assert horner(t, x) * (pow(x, n, R) - 1) % R == num
+    bad = list(inp["cols"][2]); bad[1] = (bad[1] + 1) % R
+    rc, _ = orc.quotient_coset(cols[0], cols[1], orc.fr_from_ints(bad), cols[3], cols[4], orc.fr_from_ints(z_vals[:n]),
+                               np.array(inp["sigma"], dtype=np.uint64), f(beta), f(gamma), f(alpha))
+    assert rc == 1
