@@ -256,6 +256,11 @@ class Context:
         self._ck(self.lib.plk_poly_eval(self.h, _ptr(c) if len(c) else None, C.c_uint64(len(c)), _ptr(_fr(x, (4,))), _ptr(out)))
         return out
 
+    def poly_eval_dev(self, d_coeffs, length, x):
+        out = np.empty(4, dtype=np.uint64)
+        self._ck(self.lib.plk_poly_eval_dev(self.h, _vp(d_coeffs), C.c_uint64(length), _ptr(_fr(x, (4,))), _ptr(out)))
+        return out
+
     # ---- KZG
     def kzg_commit(self, coeffs, blind):
         c = _fr(coeffs); out = np.empty(8, dtype=np.uint64); inf = C.c_int32(0)

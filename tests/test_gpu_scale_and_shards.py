@@ -204,6 +204,53 @@ def test_stress_ntt_2p24_coset_round_trip(orc):
     ctx.close()
 
 
+def test_extended_quotient_2p18_identity(orc):
+    """plk_quotient_coset at 2^18 gates (4n = 2^20 coset points), where the oracle's division takes too long: the quotient must
+    satisfy t(x) (x^n - 1) = num(x) at a random point.  Every evaluation on the right comes from an inverse NTT and a Horner
+    sweep (other kernels than the coset path); the final arithmetic is done with Python integers."""
+    import time
+    from plonk_amd.hip import Context
+    log_n = 18
+    n, R = 1 << log_n, pm.R_MOD
+    variables, gates = synth.synthetic_circuit(log_n, seed=5)
+    tb = synth.circuit_tables(variables, gates)
+    ctx = Context(0)
+    beta, gamma, alpha, xm = synth.seeded_scalars(4, 77)
+    bi, gi, ai, x = synth.from_mont(np.stack([beta, gamma, alpha, xm]))
+    zv, _ = orc.grand_product(tb["witness_flat"], tb["sigma"], beta, gamma)
+    d = {k: ctx.upload(v) for k, v in dict(a=tb["a"], b=tb["b"], c=tb["c"], qa=tb["q_add_vals"], qm=tb["q_mul_vals"], z=zv).items()}
+    d_sigma = ctx.upload(tb["sigma"])
+    d_t = ctx.malloc(4 * n * 32)
+    ctx.quotient_coset_dev(d["a"], d["b"], d["c"], d["qa"], d["qm"], d["z"], d_sigma, log_n, beta, gamma, alpha, d_t)   # warm-up: tables
+    t0 = time.perf_counter()
+    ctx.quotient_coset_dev(d["a"], d["b"], d["c"], d["qa"], d["qm"], d["z"], d_sigma, log_n, beta, gamma, alpha, d_t)
+    print("extended quotient, 2^18 gates: %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+    t = ctx.download(d_t, (4 * n, 4))
+    assert not t[3 * n - 3:].any() and t[:3 * n - 3].any()
+    w = pow(5, (R - 1) // n, R)
+
+    def at(dptr, point):                                   # interpolant of the n values at dptr, evaluated at `point`
+        ctx.ntt_dev(dptr, log_n, inverse=True)
+        v = synth.from_mont(ctx.poly_eval_dev(dptr, n, synth.to_mont([point])[0]))[0]
+        ctx.ntt_dev(dptr, log_n)
+        return v
+    A, B, C_, QA, QM = (at(d[k], x) for k in ("a", "b", "c", "qa", "qm"))
+    lhs, rhs = at(d["z"], x), at(d["z"], w * x % R)
+    sig = tb["sigma"].astype(np.int64).reshape(n, 3)
+    for k, wv in enumerate((A, B, C_)):
+        d_id = ctx.upload(synth.to_mont((3 * np.arange(n) + k).tolist()))
+        d_sg = ctx.upload(synth.to_mont(sig[:, k].tolist()))
+        lhs = lhs * (wv + bi * at(d_id, x) + gi) % R
+        rhs = rhs * (wv + bi * at(d_sg, x) + gi) % R
+        ctx.free(d_id); ctx.free(d_sg)
+    num = (QA * (A + B - C_) + QM * (A * B - C_) + ai * (lhs - rhs)) % R
+    tx = synth.from_mont(ctx.poly_eval_dev(d_t, 4 * n, xm))[0]
+    assert tx * (pow(x, n, R) - 1) % R == num
+    for p in list(d.values()) + [d_sigma, d_t]:
+        ctx.free(p)
+    ctx.close()
+
+
 def test_two_logical_shards_on_one_device(orc):
     """Point-range sharding without a second GPU: two contexts each hold half of the SRS; partial sums add up to the full MSM."""
     from plonk_amd.hip import Context
