@@ -108,6 +108,10 @@ int32_t plk_grand_product(plk_ctx* ctx, const uint64_t* witness_flat_host, const
                           const uint64_t beta[4], const uint64_t gamma[4], uint64_t* z_coeffs_out_host);
 int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n,
                               const uint64_t beta[4], const uint64_t gamma[4], void* z_coeffs_out_dev);
+/* The same, also handing out the values z[0..n) on H that the interpolation starts from: the prover's
+ * z_vals = domain.fft(&z_poly.coeffs) (src/prover.rs:237) are exactly these, so the forward transform can be skipped. */
+int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n,
+                                     const uint64_t beta[4], const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev);
 
 /* ---- Circuit::build_quotient_polynomial (src/circuit.rs:442-489) incl. build_permutation_constraint (:343-405)
  * and the all-zero public-input polynomial of src/prover.rs:224-227.  Columns are values on H (n each).

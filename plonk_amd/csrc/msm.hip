@@ -19,6 +19,7 @@
 #include "host_math.hpp"
 #include "kernels.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace plk {
 
@@ -636,18 +637,36 @@ extern "C" int32_t plk_srs_read(plk_ctx* ctx, int32_t which, uint64_t first, uin
 extern "C" int32_t plk_msm_partial_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k, uint64_t base_offset, uint64_t out_xyzz[16]) {
     if (!ctx || !out_xyzz || (k && !scalars_dev)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
-    int si;
-    PLK_TRY(msm_acquire_slot(ctx, &si));
-    MsmSlot& s = ctx->slot[si];
     PLK_HIP(hipStreamSynchronize(ctx->stream));   // scalars may have been produced on the compute stream
-    s.busy = true;
-    PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)scalars_dev, k, base_offset, 0));
-    host::pt r;
-    const int32_t rc = msm_wait(ctx, s, &r);
-    s.busy = false;
+    // A long MSM is cut into point ranges that go through the pipeline like independent MSMs: the sort of range i + 1 and the
+    // reduction of range i - 1 run beside the accumulation of range i, instead of three stages one after the other.
+    constexpr uint64_t RANGE = 1ull << 20;
+    const uint64_t nranges = k <= RANGE + RANGE / 2 ? 1 : std::min<uint64_t>((k + RANGE - 1) / RANGE, MSM_SLOTS);
+    const uint64_t per = (k + nranges - 1) / nranges;
+    int slots[MSM_SLOTS];
+    uint64_t used = 0;
+    int32_t rc = PLK_OK;
+    for (uint64_t i = 0; i < nranges && rc == PLK_OK; ++i) {
+        const uint64_t first = i * per, len = std::min(per, k - first);
+        rc = msm_acquire_slot(ctx, &slots[used]);
+        if (rc != PLK_OK) break;
+        MsmSlot& s = ctx->slot[slots[used]];
+        s.busy = true;
+        ++used;
+        rc = msm_enqueue(ctx, s, (const uint32_t*)scalars_dev + 8 * first, len, base_offset + first, 0);
+    }
+    host::pt total = host::pt_inf();
+    for (uint64_t i = 0; i < used; ++i) {   // every slot that was handed out is waited for, also after an error
+        MsmSlot& s = ctx->slot[slots[i]];
+        host::pt r;
+        const int32_t rc_wait = msm_wait(ctx, s, &r);
+        s.busy = false;
+        if (rc == PLK_OK) rc = rc_wait;
+        if (rc == PLK_OK) total = host::pt_add(total, r);
+    }
     PLK_TRY(rc);
     prof_collect(ctx, false);
-    host::pt_store(r, out_xyzz);
+    host::pt_store(total, out_xyzz);
     return PLK_OK;
 }
 extern "C" int32_t plk_g1_sum_partials(const uint64_t* xyzz, uint64_t count, uint64_t out_xy[8], int32_t* out_is_inf) {

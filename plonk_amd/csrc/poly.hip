@@ -442,8 +442,14 @@ static int32_t read_flag(plk_ctx* ctx, uint32_t* out) {
     return PLK_OK;
 }
 
+extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
+                                                const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev);
 extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
                                          const uint64_t gamma[4], void* z_coeffs_out_dev) {
+    return plk_grand_product_values_dev(ctx, witness_flat_dev, sigma_dev, log_n, beta, gamma, nullptr, z_coeffs_out_dev);
+}
+extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
+                                                const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev) {
     if (!ctx || !witness_flat_dev || !sigma_dev || !beta || !gamma || !z_coeffs_out_dev || log_n > 26) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
@@ -474,6 +480,7 @@ extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_
     hipLaunchKernelGGL(k_gp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, num, den, n, w8_of(dinv), (uint32_t*)z_coeffs_out_dev);
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
+    if (z_vals_out_dev) PLK_HIP(hipMemcpyAsync(z_vals_out_dev, z_coeffs_out_dev, n * 32, hipMemcpyDeviceToDevice, st));   // z on H, before the interpolation
     PLK_TRY(ntt_run(ctx, st, (uint32_t*)z_coeffs_out_dev, log_n, true, nullptr));
     PLK_HIP(hipStreamSynchronize(st));
     prof_collect(ctx, false);

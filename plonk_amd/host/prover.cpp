@@ -107,6 +107,19 @@ void finish_points(const KZGProverKey& pk, const int32_t* tickets, int count, bo
         check(ctx, plk_g1_sum_partials(one.data(), pk.world_size, out[i].xy, &out[i].infinity));
     }
 }
+// Order in which the independent MSMs of one round are enqueued (results do not depend on it).  One ordinary-sized MSM leads so
+// that the accumulation stream starts after a short sort; the MSMs of a handful of terms follow at once, so that their
+// reductions are long done when the round ends instead of queueing behind everybody else's on the reduction stream; two more
+// ordinary ones keep the accumulation stream busy while the long sort of the 4n-sized s_sigma runs; the rest longest first.
+void msm_order(int* order, int count, const uint64_t* len) {
+    std::vector<int> tiny, rest;
+    for (int i = 1; i < count; ++i) (len[i] <= 16 ? tiny : rest).push_back(i);
+    if (rest.size() > 2) std::stable_sort(rest.begin() + 2, rest.end(), [&](int x, int y) { return len[x] > len[y]; });
+    int k = 0;
+    order[k++] = 0;
+    for (int i : tiny) order[k++] = i;
+    for (int i : rest) order[k++] = i;
+}
 G1Affine finish_point(const KZGProverKey& pk, int32_t ticket) {
     G1Affine out;
     finish_points(pk, &ticket, 1, false, &out, nullptr, nullptr);
@@ -138,13 +151,19 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
         for (int i = 0; i < 7; ++i)
             for (auto& r : blind[i]) r = rng();
         int order[7] = {0, 1, 2, 3, 4, 5, 6};
-        // three ordinary-sized MSMs lead so that the accumulation stream starts after a short sort and the long sort of the
-        // 4n-sized s_sigma hides behind them; the rest follows longest first
-        std::stable_sort(order + 3, order + 7, [&](int x, int y) { return in.len[x] > in.len[y]; });
+        msm_order(order, 7, in.len);
         int32_t ticket[7];
         for (int k = 0; k < 7; ++k) {
             const int i = order[k];
             check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
+        }
+        // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233) depend on no challenge: they are enqueued here,
+        // behind the sorts, and run beside the accumulation kernels instead of on the critical path between rounds 2 and 4.
+        if (in.len[0] >= n && in.len[1] >= n && in.len[2] >= n) {
+            check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
+            check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
+            check(ctx, plk_ntt_dev_enqueue(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
+            check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
         }
         G1Affine c7[7];
         finish_points(pk, ticket, 7, false, c7, nullptr, nullptr);
@@ -163,8 +182,9 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
 
     // ---- round 2: grand product z, commit :205-216.  The commitment's MSM runs on its own stream while round 3's
     // transforms and pointwise pass (which need z but not its commitment) use the compute stream.
+    // z_vals = domain.fft(&z_poly.coeffs) (:237) are the values the interpolation started from: kept in work[3], no transform.
     void* z_coeffs = in.work[2];
-    check(ctx, plk_grand_product_dev(ctx, in.witness_flat, in.sigma, log_n, beta.v, gamma.v, z_coeffs));
+    check(ctx, plk_grand_product_values_dev(ctx, in.witness_flat, in.sigma, log_n, beta.v, gamma.v, in.work[3], z_coeffs));
     for (auto& r : blind[7]) r = rng();
     int32_t z_ticket;
     check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
@@ -176,12 +196,6 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
     try {
         if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
             throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
-        check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
-        check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
-        check(ctx, plk_copy_dev(ctx, in.work[3], z_coeffs, n * 32, n * 32));
-        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
-        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
-        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[3], log_n, 0, nullptr));            // z values     :237
         check(ctx, plk_quotient_dev(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4],
                                     &t_len));
         for (auto& r : blind[8]) r = rng();
@@ -204,7 +218,7 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
         const void* polys[9] = {in.poly[0], in.poly[1], in.poly[2], in.poly[3], in.poly[4], in.poly[5], in.poly[6], z_coeffs, in.work[4]};
         const uint64_t lens[9] = {in.len[0], in.len[1], in.len[2], in.len[3], in.len[4], in.len[5], in.len[6], n, t_len};
         int order[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
-        std::stable_sort(order + 3, order + 9, [&](int x, int y) { return lens[x] > lens[y]; });
+        msm_order(order, 9, lens);
         int32_t ticket[9];
         for (int k = 0; k < 9; ++k) {
             const int i = order[k];
