@@ -90,7 +90,7 @@ struct plk_ctx {
     uint32_t* tables = nullptr;        // [MSM_WINDOWS][table_stride] affine, 16 words each, x*2^261 form
     // NTT
     std::map<int, uint32_t*> twiddles; // log_n -> w^i for i < n/2, x*2^261 form
-    std::map<std::vector<uint64_t>, uint32_t*> coset_factors;   // (log_n, inverse, generator) -> g^i, or n^-1 g^-i, i < n (x*2^261 form)
+    std::map<std::vector<uint64_t>, uint32_t*> coset_factors;   // per-element factor tables of the large transforms (x*2^261 form): (log_n, inverse, generator) -> g^i or n^-1 g^-i; (~0, log_n, inverse, pass, ...) -> inter-pass twiddles
     uint32_t* ntt_tmp[2] = {nullptr, nullptr};
     uint64_t ntt_tmp_cap = 0;
     // scratch for pointwise / scan kernels

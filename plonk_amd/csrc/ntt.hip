@@ -185,7 +185,7 @@ __device__ __forceinline__ void ntt8_stages(fe* x, const uint32_t* tw, uint32_t 
 }
 
 // one visit of the registers after the first: every thread takes 8 >> Q groups of 2^Q elements, one after the other
-template <int Q, bool OUT_F>
+template <int Q, bool OUT_F, bool TW_T>
 __device__ __forceinline__ void ntt8_subpass(uint32_t* lds, const uint32_t* tw, const Ntt8Pass& a, uint32_t s, bool final_sub, const uint32_t* __restrict__ W,
                                              uint32_t* __restrict__ out, const fe& sc, const uint32_t* __restrict__ out_factors) {
     constexpr int G = 8 >> Q, E = 1 << Q;
@@ -211,8 +211,8 @@ __device__ __forceinline__ void ntt8_subpass(uint32_t* lds, const uint32_t* tw, 
         }
         const uint64_t j = (uint64_t)blockIdx.x * T + jj;
         const uint64_t j0 = ((j >> a.log_ns) << (a.log_ns + log_r)) | (j & ns_mask);
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
+        static_for<E>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
             const uint32_t u = pos0 + ((uint32_t)m << s);
             const uint64_t o = j0 + ((uint64_t)u << a.log_ns);
             uint32_t* dst = out + 8ull * o;
@@ -220,22 +220,29 @@ __device__ __forceinline__ void ntt8_subpass(uint32_t* lds, const uint32_t* tw, 
                 if constexpr (OUT_F) st_fe<FrP>(dst, mul<FrP>(x[m], ld_fe(out_factors + 8ull * o)));   // inverse coset: n^-1 g^-o
                 else st_fe<FrP>(dst, mul<FrP>(x[m], sc));
             } else {
-                const uint32_t lns2 = a.log_ns + log_r;
-                const uint32_t t2 = (uint32_t)(o >> (a.log_n - a.next_log_r)), k2 = (uint32_t)o & ((1u << lns2) - 1);
-                fe w = sc;   // 1
-                if (t2 != 0 && k2 != 0) w = twiddle_operand(W, (k2 * t2) << (a.log_n - lns2 - a.next_log_r), a.log_n, a.inverse);
-                const fe y = mul<FrP>(x[m], w);
+                fe y;
+                if constexpr (TW_T) {
+                    y = mul<FrP>(x[m], ld_fe(out_factors + 8ull * o));   // the next pass's factors, laid out in this pass's output order
+                } else {
+                    const uint32_t lns2 = a.log_ns + log_r;
+                    const uint32_t t2 = (uint32_t)(o >> (a.log_n - a.next_log_r)), k2 = (uint32_t)o & ((1u << lns2) - 1);
+                    fe w = sc;   // 1
+                    if (t2 != 0 && k2 != 0) w = twiddle_operand(W, (k2 * t2) << (a.log_n - lns2 - a.next_log_r), a.log_n, a.inverse);
+                    y = mul<FrP>(x[m], w);
+                }
                 uint32_t wd[8];
                 pack(y, wd);
                 store8(dst, wd);
             }
-        }
+        });
     }
 }
 
 // IN_F: multiply by in_factors[i] while loading (first pass of a forward coset transform); OUT_F: the final product takes
-// out_factors[o] instead of the scale (last pass of an inverse coset transform)
-template <bool IN_F, bool OUT_F>
+// out_factors[o] instead of the scale (last pass of an inverse coset transform); TW_T: a pass that is not the last takes the
+// next pass's twiddles from out_factors[o], a table in output order that is streamed with the data, instead of gathering
+// them from the n/2 table of powers (32-byte reads all over a table of up to n * 16 bytes: twice the data's own traffic).
+template <bool IN_F, bool OUT_F, bool TW_T>
 __global__ void __launch_bounds__(NTT8_THREADS) k_ntt_pass8(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ W, Ntt8Pass a,
                                                             NttScale scale /* x*2^256 words */, const uint32_t* __restrict__ in_factors,
                                                             const uint32_t* __restrict__ out_factors) {
@@ -278,9 +285,9 @@ __global__ void __launch_bounds__(NTT8_THREADS) k_ntt_pass8(const uint32_t* __re
     for (uint32_t sp = 1; sp < a.nsub; ++sp) {
         const bool final_sub = sp + 1 == a.nsub;
         const uint32_t q = a.q[sp];
-        if (q == 3) ntt8_subpass<3, OUT_F>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
-        else if (q == 2) ntt8_subpass<2, OUT_F>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
-        else ntt8_subpass<1, OUT_F>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
+        if (q == 3) ntt8_subpass<3, OUT_F, TW_T>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
+        else if (q == 2) ntt8_subpass<2, OUT_F, TW_T>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
+        else ntt8_subpass<1, OUT_F, TW_T>(lds, tw, a, s, final_sub, W, out, sc, out_factors);
         s += q;
         if (!final_sub) __syncthreads();
     }
@@ -384,6 +391,17 @@ __global__ void __launch_bounds__(256) k_ntt_cross(uint32_t* __restrict__ data, 
     });
 }
 
+// out[o] = the factor the pass after this one applies to element o: w^(+-(o mod Ns') (o div N/R') N/(Ns' R')), canonical, x*2^261 form
+__global__ void __launch_bounds__(256) k_pass_twiddles(uint32_t* __restrict__ out, const uint32_t* __restrict__ W, uint32_t log_n, uint32_t next_log_r, uint32_t lns2,
+                                                       int inverse) {
+    const uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (1ull << log_n)) return;
+    const uint32_t t2 = (uint32_t)(o >> (log_n - next_log_r)), k2 = (uint32_t)o & ((1u << lns2) - 1);
+    fe w = fe_const(FrP::ONE);
+    if (t2 != 0 && k2 != 0) { w = twiddle_operand(W, (k2 * t2) << (log_n - lns2 - next_log_r), log_n, inverse); norm(w); }
+    st_fe<FrP>(out + 8ull * o, w);
+}
+
 static host::el root_of_unity(uint32_t log_n) {
     static const uint64_t ROOT28[4] = {0x636e735580d13d9cULL, 0xa22bf3742445ffd6ULL, 0x56452ac01eb203d8ULL, 0x1860ef942963f9e7ULL};
     host::el w = host::el_load(ROOT28);
@@ -441,6 +459,24 @@ static int32_t coset_factors(plk_ctx* ctx, hipStream_t st, uint32_t log_n, bool 
     uint32_t* table = nullptr;
     if (hipMalloc(&table, n * 32) != hipSuccess) { ctx->err = "out of device memory for the coset factors"; return PLK_ERR_ALLOC; }
     hipLaunchKernelGGL(k_power_table, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, table, n, power_args(g, base));
+    PLK_HIP(hipGetLastError());
+    ctx->coset_factors[key] = table;
+    *out = table;
+    return PLK_OK;
+}
+
+// Twiddles between pass p and pass p + 1 of a transform of 2^log_n elements in pass p's output order, built once and kept
+// (n * 32 bytes per pass boundary and direction; HBM capacity buys the coalesced access).
+constexpr uint32_t NTT_TABLE_MAX_LOG_N = 25;
+static int32_t pass_twiddles(plk_ctx* ctx, hipStream_t st, const uint32_t* W, uint32_t log_n, bool inverse, uint32_t p, uint32_t next_log_r, uint32_t lns2,
+                             const uint32_t** out) {
+    std::vector<uint64_t> key = {0xffffffffffffffffull, log_n, inverse ? 1ull : 0ull, p, next_log_r, lns2};
+    auto it = ctx->coset_factors.find(key);
+    if (it != ctx->coset_factors.end()) { *out = it->second; return PLK_OK; }
+    const uint64_t n = 1ull << log_n;
+    uint32_t* table = nullptr;
+    if (hipMalloc(&table, n * 32) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return PLK_OK; }   // no room: the pass gathers instead
+    hipLaunchKernelGGL(k_pass_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, W, log_n, next_log_r, lns2, inverse ? 1 : 0);
     PLK_HIP(hipGetLastError());
     ctx->coset_factors[key] = table;
     *out = table;
@@ -507,9 +543,19 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
                 left -= q;
             }
             const dim3 grid((uint32_t)(n / NTT8_TILE)), block(NTT8_THREADS);
-            if (factors && p == 0 && !inverse) hipLaunchKernelGGL((k_ntt_pass8<true, false>), grid, block, 0, st, src, dst, W, a, ninv, factors, nullptr);
-            else if (factors && last && inverse) hipLaunchKernelGGL((k_ntt_pass8<false, true>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, factors);
-            else hipLaunchKernelGGL((k_ntt_pass8<false, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, nullptr);
+            const uint32_t* tw_next = nullptr;
+            if (!last && log_n <= NTT_TABLE_MAX_LOG_N) PLK_TRY(pass_twiddles(ctx, st, W, log_n, inverse, p, lr[p + 1], lns[p] + lr[p], &tw_next));
+            const bool in_f = factors && p == 0 && !inverse;
+            if (last) {
+                if (factors && inverse) hipLaunchKernelGGL((k_ntt_pass8<false, true, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, factors);
+                else hipLaunchKernelGGL((k_ntt_pass8<false, false, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, nullptr);
+            } else if (tw_next) {
+                if (in_f) hipLaunchKernelGGL((k_ntt_pass8<true, false, true>), grid, block, 0, st, src, dst, W, a, ninv, factors, tw_next);
+                else hipLaunchKernelGGL((k_ntt_pass8<false, false, true>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, tw_next);
+            } else {
+                if (in_f) hipLaunchKernelGGL((k_ntt_pass8<true, false, false>), grid, block, 0, st, src, dst, W, a, ninv, factors, nullptr);
+                else hipLaunchKernelGGL((k_ntt_pass8<false, false, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, nullptr);
+            }
         }
         src = dst;
     }

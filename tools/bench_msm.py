@@ -14,10 +14,38 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--log-n", type=int, default=20)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ntt", action="store_true")
+ap.add_argument("--quotient", action="store_true", help="time the extended-coset quotient of a 2^(log_n - 2)-gate circuit (4n = 2^log_n coset points) instead of the MSM")
 ap.add_argument("--batch", type=int, default=0, help="also time this many hiding commitments in flight at once")
 args = ap.parse_args()
 n = 1 << args.log_n
 ctx = Context(0)
+if args.quotient:
+    # synthetic columns: the kernels do the same work whatever the values are; status NOT_DIVISIBLE is expected and ignored
+    from plonk_amd.hip import PlonkHipError
+    gates = n // 4
+    rng = np.random.default_rng(4)
+    def col():
+        raw = rng.integers(0, 1 << 63, size=(gates, 4), dtype=np.uint64); raw[:, 3] &= np.uint64((1 << 60) - 1); return ctx.upload(raw)
+    cols = [col() for _ in range(6)]
+    d_sigma = ctx.upload(rng.permutation(3 * gates).astype(np.uint64))
+    d_t = ctx.malloc(n * 32)
+    bga = synth.seeded_scalars(3, 9)
+    def run():
+        try:
+            ctx.quotient_coset_dev(*cols, d_sigma, args.log_n - 2, bga[0], bga[1], bga[2], d_t)
+        except PlonkHipError as e:
+            assert e.status == "PLK_ERR_NOT_DIVISIBLE"
+    run(); ctx.profile_enable(True); ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        run()
+    wall = (time.perf_counter() - t0) / args.reps
+    pw, pc = ctx.profile_get("pointwise"); nt, nc = ctx.profile_get("ntt")
+    # k_quotient_coset: 11 reads + 1 write of 32 B per coset point
+    print(json.dumps({"log_coset_points": args.log_n, "gates": gates, "wall_ms": round(wall * 1e3, 3), "pointwise_ms_per_call": round(pw / args.reps, 4),
+                      "ntt_ms_per_call": round(nt / args.reps, 4), "ntt_launches_per_call": nc // args.reps,
+                      "quotient_kernel_algorithmic_bytes": 12 * 32 * n}))
+    sys.exit(0)
 tau, gs = synth.seeded_scalars(2, 7)
 t0 = time.perf_counter(); ctx.srs_generate(tau, gs, n); t_srs = time.perf_counter() - t0
 rng = np.random.default_rng(2)
