@@ -75,6 +75,31 @@ int32_t plonk_prove(void* pk, void* inputs, const uint64_t* public_inputs, uint6
     });
 }
 
+// src/verifier.rs:57 on serialized proof bytes, with the verifier key of the synthetic SRS (tau, gscal).  *ok = 1 when all nine openings check.
+int32_t plonk_verify(const uint64_t* tau, const uint64_t* gscal, const uint8_t* proof_bytes, uint64_t proof_len, const uint64_t* public_inputs, uint64_t n_public,
+                     const uint64_t* opening_challenge, int32_t* ok) {
+    return guarded([&] {
+        Fr t, g, c;
+        memcpy(t.v, tau, 32); memcpy(g.v, gscal, 32); memcpy(c.v, opening_challenge, 32);
+        std::vector<Fr> pub(n_public);
+        if (n_public) memcpy(pub.data(), public_inputs, n_public * 32);
+        const PlonkProof proof = deserialize_proof(proof_bytes, proof_len);
+        *ok = verify_plonk_proof_with_transcript(verifier_key_from_trapdoor(t, g), proof, pub, c) ? 1 : 0;
+    });
+}
+int32_t plonk_pairing_selftest(const uint64_t* a, const uint64_t* b) {
+    Fr x, y;
+    memcpy(x.v, a, 32); memcpy(y.v, b, 32);
+    return pairing_selftest(x, y) ? 1 : 0;
+}
+// serialize(deserialize(bytes)) for the tests: 0 when the bytes decode and re-encode to themselves
+int32_t plonk_proof_roundtrip(const uint8_t* proof_bytes, uint64_t len) {
+    return guarded([&] {
+        const std::vector<uint8_t> again = serialize_proof(deserialize_proof(proof_bytes, len));
+        if (again.size() != len || memcmp(again.data(), proof_bytes, len) != 0) throw Error(PLK_ERR_INVALID_ARG, "proof bytes do not round-trip");
+    });
+}
+
 void plonk_transcript_kat(uint8_t* out32) {
     PlonkTranscript t("test protocol");
     t.append_message("some label", reinterpret_cast<const uint8_t*>("some data"), 9);

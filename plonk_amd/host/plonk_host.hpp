@@ -139,6 +139,26 @@ DensePolynomial build_quotient_polynomial(const KZGProverKey& pk, const std::vec
 DensePolynomial interpolate_selector(const KZGProverKey& pk, const std::vector<Fr>& values);
 std::pair<DensePolynomial, DensePolynomial> interpolate_permutation_polynomials(const KZGProverKey& pk, const std::vector<uint64_t>& sigma, const Domain& domain);
 
+// ---- verifier (src/verifier.rs:57-236); CPU only
+// G2 point: x and y in Fq2 as c0 || c1 (each x * 2^256 mod q)
+struct G2Affine {
+    uint64_t x[8], y[8];
+    int32_t infinity;
+};
+// kzg10::VerifierKey { g, gamma_g, h, beta_h }
+struct KZGVerifierKey {
+    G1Affine g, gamma_g;
+    G2Affine h, beta_h;
+};
+// verifier key of the synthetic SRS of KZGProverKey::generate (what PCS::setup derives from its rng draws, src/main.rs:182)
+KZGVerifierKey verifier_key_from_trapdoor(const Fr& tau, const Fr& gscal);
+// src/verifier.rs:57: replays the transcript, then PCS::check for the nine openings (two pairings each).  opening_challenge is the
+// value the prover's and verifier's Poseidon sponges squeeze (src/verifier.rs:183-191), supplied by the caller as in the prover.
+bool verify_plonk_proof_with_transcript(const KZGVerifierKey& vk, const PlonkProof& proof, const std::vector<Fr>& public_inputs, const Fr& opening_challenge);
+// inverse of serialize_proof (ark-serialize deserialize_compressed with validation of every field element and point)
+PlonkProof deserialize_proof(const uint8_t* bytes, size_t len);
+bool pairing_selftest(const Fr& a, const Fr& b);
+
 // canonical proof bytes: the fields of PlonkProof in declaration order, each with ark-serialize's compressed encoding
 // (Fr 32 B; Commitment 33 B; Proof 65 B) = 1170 bytes
 std::vector<uint8_t> serialize_proof(const PlonkProof& p);

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libplonk_host.so")
 HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate",
                 "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
-                "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1"]
+                "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip"]
 GATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64))
 
 _host = None
@@ -149,3 +149,17 @@ class ProverKey:
         self._ck(self.lib.plonk_prove(self.h, inputs.h, _ptr(pub), C.c_uint64(0 if pub is None else len(pub)), _ptr(bl), C.c_uint64(len(bl)), _ptr(proof),
                                       _ptr(ch), _ptr(sec)))
         return ProofResult(proof.tobytes(), ch, sec)
+
+
+def verify(tau, gscal, proof_bytes: bytes, opening_challenge, public_inputs=None) -> bool:
+    """verify_plonk_proof_with_transcript (src/verifier.rs:57) on the CPU: transcript replay and nine KZG10 checks with pairings.
+    tau, gscal: trapdoor of the synthetic SRS the proof was made with (the verifier key is derived from them)."""
+    lib = load_host_library()
+    buf = np.frombuffer(proof_bytes, dtype=np.uint8).copy()
+    pub = _u64(public_inputs, (-1, 4)) if public_inputs is not None and len(public_inputs) else None
+    ok = C.c_int32(0)
+    rc = lib.plonk_verify(_ptr(_u64(tau, (4,))), _ptr(_u64(gscal, (4,))), _ptr(buf), C.c_uint64(len(buf)), _ptr(pub), C.c_uint64(0 if pub is None else len(pub)),
+                          _ptr(_u64(opening_challenge, (4,))), C.byref(ok))
+    if rc != 0:
+        raise hip.PlonkHipError(rc, (lib.plonk_host_last_error() or b"").decode())
+    return bool(ok.value)

@@ -81,3 +81,22 @@ def test_broken_witness_is_rejected(pk, orc):
         pk.prove(inputs, synth.seeded_scalars(27, 4))
     assert e.value.status == "PLK_ERR_NOT_DIVISIBLE" and "not divisible by Z_H" in str(e.value)
     inputs.close()
+
+
+@pytest.mark.parametrize("log_n", [2, 14])
+def test_gpu_proof_passes_the_pairing_verifier(pk, orc, log_n):
+    """src/main.rs:211-230: prove, then verify_plonk_proof_with_transcript.  The verifier runs on the CPU with real pairings, so
+    this needs neither the oracle nor the SRS trapdoor identities the other tests use."""
+    from plonk_amd import prover
+    variables, gates = synth.example_circuit() if log_n == 2 else synth.synthetic_circuit(log_n, seed=77)
+    tables = synth.circuit_tables(variables, gates)
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
+    chal = orc.fr_from_ints([0x1234567890ABCDEF1122334455667788])[0]
+    pk.set_opening_challenge(chal)
+    inputs = pk.prepare(tables)
+    proof = pk.prove(inputs, synth.seeded_scalars(27, 6)).proof_bytes
+    inputs.close()
+    assert prover.verify(tau, gs, proof, chal) is True
+    bad = bytearray(proof); bad[40] ^= 0x10
+    assert prover.verify(tau, gs, bytes(bad), chal) is False

@@ -219,3 +219,37 @@ def test_point_range_shards_combine_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_pairing_is_bilinear():
+    """The host verifier's ate pairing: e(aG, bH) = e(G, H)^(ab) and e(G, H) != 1."""
+    from plonk_amd import prover
+    lib = prover.load_host_library()
+    for a, b in ((1, 1), (2, 3), (pm.R_MOD - 1, 5), (0x123456789ABCDEF, pm.R_MOD - 2)):
+        am, bm = synth.to_mont([a])[0], synth.to_mont([b])[0]
+        assert lib.plonk_pairing_selftest(am.ctypes.data_as(C.c_void_p), bm.ctypes.data_as(C.c_void_p)) == 1
+
+
+def test_example_circuit_proved_and_verified_on_the_cpu(orc):
+    """BASELINE configs[0]: the reference's example circuit (src/main.rs:29-39) proved by the CPU oracle, then verified by the host
+    verifier (src/verifier.rs:57-236: transcript replay + nine KZG10 pairing checks), no GPU and no trapdoor shortcut involved."""
+    import json
+    from plonk_amd import prover
+    p = json.load(open(os.path.join(ROOT, "tests", "golden", "proofs.json")))[0]
+    proof = bytes.fromhex(p["proof_hex"])
+    tau, gs, chal = (synth.to_mont([int(p[k], 0)])[0] for k in ("tau", "gscal", "chal"))
+    lib = prover.load_host_library()
+    buf = np.frombuffer(proof, dtype=np.uint8).copy()
+    assert lib.plonk_proof_roundtrip(buf.ctypes.data_as(C.c_void_p), C.c_uint64(len(buf))) == 0
+    assert prover.verify(tau, gs, proof, chal) is True
+    # any change to an evaluation, a commitment, an opening, the challenge or the trapdoor must be rejected
+    bad = bytearray(proof); bad[0] ^= 1
+    assert prover.verify(tau, gs, bytes(bad), chal) is False
+    bad = bytearray(proof); bad[9 * 32 + 9 * 33 + 33 + 5] ^= 1          # random_v of the first opening
+    assert prover.verify(tau, gs, bytes(bad), chal) is False
+    assert prover.verify(tau, gs, proof, synth.to_mont([int(p["chal"], 0) + 1])[0]) is False
+    assert prover.verify(synth.to_mont([int(p["tau"], 0) + 1])[0], gs, proof, chal) is False
+    # swapping two commitments keeps every point valid but breaks the openings
+    bad = bytearray(proof); o = 9 * 32
+    bad[o:o + 33], bad[o + 33:o + 66] = proof[o + 33:o + 66], proof[o:o + 33]
+    assert prover.verify(tau, gs, bytes(bad), chal) is False
