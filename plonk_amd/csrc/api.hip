@@ -289,11 +289,9 @@ extern "C" int32_t plk_kzg_commit_dev(plk_ctx* ctx, const void* coeffs_dev, uint
 extern "C" int32_t plk_kzg_commit(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t* blind, uint64_t out_xy[8], int32_t* out_is_inf) {
     if (!ctx || (len && !coeffs_host)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
-    void* d = nullptr;
-    if (len) { PLK_HIP(hipMalloc(&d, len * 32)); PLK_HIP(hipMemcpy(d, coeffs_host, len * 32, hipMemcpyHostToDevice)); }
-    const int32_t rc = plk_kzg_commit_dev(ctx, d, len, blind, out_xy, out_is_inf);
-    if (d) hipFree(d);
-    return rc;
+    DevBuf d;
+    if (len) PLK_HIP(d.alloc_copy(coeffs_host, len * 32));
+    return plk_kzg_commit_dev(ctx, d.p, len, blind, out_xy, out_is_inf);
 }
 
 // ---- KZG open --------------------------------------------------------------------------------------
@@ -366,9 +364,7 @@ extern "C" int32_t plk_kzg_open(plk_ctx* ctx, const uint64_t* coeffs_host, uint6
                                 const uint64_t challenge[4], uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]) {
     if (!ctx || (len && !coeffs_host)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
-    void* d = nullptr;
-    if (len) { PLK_HIP(hipMalloc(&d, len * 32)); PLK_HIP(hipMemcpy(d, coeffs_host, len * 32, hipMemcpyHostToDevice)); }
-    const int32_t rc = plk_kzg_open_dev(ctx, d, len, blind, zeta, challenge, w_xy, w_is_inf, random_v, eval);
-    if (d) hipFree(d);
-    return rc;
+    DevBuf d;
+    if (len) PLK_HIP(d.alloc_copy(coeffs_host, len * 32));
+    return plk_kzg_open_dev(ctx, d.p, len, blind, zeta, challenge, w_xy, w_is_inf, random_v, eval);
 }

@@ -120,6 +120,21 @@ int32_t set_err(plk_ctx* ctx, int32_t code, const char* what, hipError_t e, int 
         if (rc_ != PLK_OK) return rc_;     \
     } while (0)
 
+// Device allocation that is released when the scope ends, for the entry points that stage host buffers and may return early.
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 32); }
+    hipError_t alloc_copy(const void* host, size_t bytes) {
+        const hipError_t e = alloc(bytes);
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
+    }
+};
+
 // profiling brackets (no-ops unless enabled)
 void prof_begin(plk_ctx* ctx, hipStream_t s, const char* name);
 void prof_end(plk_ctx* ctx, hipStream_t s);

@@ -547,13 +547,13 @@ extern "C" int32_t plk_srs_load_shard(plk_ctx* ctx, const uint64_t* g_xy_host, u
     PLK_TRY(srs_alloc(ctx, shard_first, shard_len, total_len));
     if (ctx->has_gamma && !gamma_g_xy_host) { ctx->err = "the shard holding index 0 needs the gamma powers"; return PLK_ERR_INVALID_ARG; }
     const uint64_t cnt = ctx->has_gamma ? shard_len + 3 : shard_len;
-    uint32_t* staging = nullptr;
-    PLK_HIP(hipMalloc(&staging, cnt * 64));
+    DevBuf staging_buf;
+    PLK_HIP(staging_buf.alloc(cnt * 64));
+    uint32_t* staging = (uint32_t*)staging_buf.p;
     PLK_HIP(hipMemcpyAsync(staging, g_xy_host, shard_len * 64, hipMemcpyHostToDevice, ctx->stream));
     if (ctx->has_gamma) PLK_HIP(hipMemcpyAsync(staging + 16 * shard_len, gamma_g_xy_host, 3 * 64, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_fq_to_rp, dim3((unsigned)((cnt * 2 + 255) / 256)), dim3(256), 0, ctx->stream, staging, ctx->tables, cnt * 2);
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    PLK_HIP(hipFree(staging));
     return srs_build_tables(ctx);
 }
 extern "C" int32_t plk_srs_load(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t len, const uint64_t* gamma_g_xy_host) {
@@ -624,12 +624,13 @@ extern "C" int32_t plk_srs_read(plk_ctx* ctx, int32_t which, uint64_t first, uin
         off = ctx->shard_len + first;
     }
     if (count == 0) return PLK_OK;
-    uint32_t* tmp = nullptr;
-    PLK_HIP(hipMalloc(&tmp, count * 64));
+    DevBuf tmp_buf;
+    PLK_HIP(tmp_buf.alloc(count * 64));
+    uint32_t* tmp = (uint32_t*)tmp_buf.p;
     hipLaunchKernelGGL(k_fq_to_r, dim3((unsigned)((count * 2 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->tables + 16 * off, tmp, count * 2);
+    PLK_HIP(hipGetLastError());
     PLK_HIP(hipMemcpyAsync(out_xy_host, tmp, count * 64, hipMemcpyDeviceToHost, ctx->stream));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    PLK_HIP(hipFree(tmp));
     return PLK_OK;
 }
 
@@ -684,12 +685,7 @@ extern "C" int32_t plk_msm_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k
 extern "C" int32_t plk_msm(plk_ctx* ctx, const uint64_t* scalars_host, uint64_t k, uint64_t base_offset, uint64_t out_xy[8], int32_t* out_is_inf) {
     if (!ctx || (k && !scalars_host)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
-    void* d = nullptr;
-    if (k) {
-        PLK_HIP(hipMalloc(&d, k * 32));
-        PLK_HIP(hipMemcpy(d, scalars_host, k * 32, hipMemcpyHostToDevice));
-    }
-    const int32_t rc = plk_msm_dev(ctx, d, k, base_offset, out_xy, out_is_inf);
-    if (d) hipFree(d);
-    return rc;
+    DevBuf d;
+    if (k) PLK_HIP(d.alloc_copy(scalars_host, k * 32));
+    return plk_msm_dev(ctx, d.p, k, base_offset, out_xy, out_is_inf);
 }

@@ -587,13 +587,11 @@ extern "C" int32_t plk_ntt(plk_ctx* ctx, uint64_t* data_host, uint32_t log_n, in
     if (!ctx || !data_host || log_n > 27) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)32 << log_n;
-    void* d = nullptr;
-    PLK_HIP(hipMalloc(&d, bytes));
-    PLK_HIP(hipMemcpy(d, data_host, bytes, hipMemcpyHostToDevice));
-    int32_t rc = plk_ntt_dev(ctx, d, log_n, inverse, coset_gen);
-    if (rc == PLK_OK && hipMemcpy(data_host, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
-    hipFree(d);
-    return rc;
+    DevBuf d;
+    PLK_HIP(d.alloc_copy(data_host, bytes));
+    PLK_TRY(plk_ntt_dev(ctx, d.p, log_n, inverse, coset_gen));
+    PLK_HIP(hipMemcpy(data_host, d.p, bytes, hipMemcpyDeviceToHost));
+    return PLK_OK;
 }
 
 extern "C" int32_t plk_scale_powers_dev(plk_ctx* ctx, void* data_dev, uint64_t n, const uint64_t base[4], const uint64_t ratio[4]) {

@@ -400,17 +400,16 @@ extern "C" int32_t plk_field_op(plk_ctx* ctx, int32_t field, int32_t op, const u
     if (!ctx || !a_host || !b_host || !out_host || op < 0 || op > 2) return PLK_ERR_INVALID_ARG;
     if (n == 0) return PLK_OK;
     PLK_HIP(hipSetDevice(ctx->device));
-    uint32_t *a, *b, *o;
-    PLK_HIP(hipMalloc(&a, n * 32)); PLK_HIP(hipMalloc(&b, n * 32)); PLK_HIP(hipMalloc(&o, n * 32));
-    PLK_HIP(hipMemcpy(a, a_host, n * 32, hipMemcpyHostToDevice));
-    PLK_HIP(hipMemcpy(b, b_host, n * 32, hipMemcpyHostToDevice));
+    DevBuf a, b, o;
+    PLK_HIP(a.alloc_copy(a_host, n * 32));
+    PLK_HIP(b.alloc_copy(b_host, n * 32));
+    PLK_HIP(o.alloc(n * 32));
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (field == 0) hipLaunchKernelGGL(k_field_op<FrP>, grid, dim3(256), 0, ctx->stream, op, a, b, o, n);
-    else hipLaunchKernelGGL(k_field_op<FqP>, grid, dim3(256), 0, ctx->stream, op, a, b, o, n);
+    if (field == 0) hipLaunchKernelGGL(k_field_op<FrP>, grid, dim3(256), 0, ctx->stream, op, (const uint32_t*)a.p, (const uint32_t*)b.p, (uint32_t*)o.p, n);
+    else hipLaunchKernelGGL(k_field_op<FqP>, grid, dim3(256), 0, ctx->stream, op, (const uint32_t*)a.p, (const uint32_t*)b.p, (uint32_t*)o.p, n);
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    PLK_HIP(hipMemcpy(out_host, o, n * 32, hipMemcpyDeviceToHost));
-    hipFree(a); hipFree(b); hipFree(o);
+    PLK_HIP(hipMemcpy(out_host, o.p, n * 32, hipMemcpyDeviceToHost));
     return PLK_OK;
 }
 
@@ -428,11 +427,9 @@ extern "C" int32_t plk_poly_eval_dev(plk_ctx* ctx, const void* coeffs_dev, uint6
 extern "C" int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t x[4], uint64_t out[4]) {
     if (!ctx || (len && !coeffs_host)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
-    void* d = nullptr;
-    if (len) { PLK_HIP(hipMalloc(&d, len * 32)); PLK_HIP(hipMemcpy(d, coeffs_host, len * 32, hipMemcpyHostToDevice)); }
-    const int32_t rc = plk_poly_eval_dev(ctx, d, len, x, out);
-    if (d) hipFree(d);
-    return rc;
+    DevBuf d;
+    if (len) PLK_HIP(d.alloc_copy(coeffs_host, len * 32));
+    return plk_poly_eval_dev(ctx, d.p, len, x, out);
 }
 
 static int32_t read_flag(plk_ctx* ctx, uint32_t* out) {
@@ -491,14 +488,13 @@ extern "C" int32_t plk_grand_product(plk_ctx* ctx, const uint64_t* witness_flat_
     if (!ctx || !witness_flat_host || !sigma_host || !z_coeffs_out_host || log_n > 26) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
-    void *w, *s, *z;
-    PLK_HIP(hipMalloc(&w, 3 * n * 32)); PLK_HIP(hipMalloc(&s, 3 * n * 8)); PLK_HIP(hipMalloc(&z, n * 32));
-    PLK_HIP(hipMemcpy(w, witness_flat_host, 3 * n * 32, hipMemcpyHostToDevice));
-    PLK_HIP(hipMemcpy(s, sigma_host, 3 * n * 8, hipMemcpyHostToDevice));
-    int32_t rc = plk_grand_product_dev(ctx, w, s, log_n, beta, gamma, z);
-    if (rc == PLK_OK && hipMemcpy(z_coeffs_out_host, z, n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
-    hipFree(w); hipFree(s); hipFree(z);
-    return rc;
+    DevBuf w, s, z;
+    PLK_HIP(w.alloc_copy(witness_flat_host, 3 * n * 32));
+    PLK_HIP(s.alloc_copy(sigma_host, 3 * n * 8));
+    PLK_HIP(z.alloc(n * 32));
+    PLK_TRY(plk_grand_product_dev(ctx, w.p, s.p, log_n, beta, gamma, z.p));
+    PLK_HIP(hipMemcpy(z_coeffs_out_host, z.p, n * 32, hipMemcpyDeviceToHost));
+    return PLK_OK;
 }
 
 extern "C" int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
@@ -537,15 +533,13 @@ extern "C" int32_t plk_quotient(plk_ctx* ctx, const uint64_t* a, const uint64_t*
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
     const uint64_t* src[6] = {a, b, c, q_add_vals, q_mul_vals, z_vals};
-    void* d[6]; void *s, *t;
-    for (int i = 0; i < 6; ++i) { PLK_HIP(hipMalloc(&d[i], n * 32)); PLK_HIP(hipMemcpy(d[i], src[i], n * 32, hipMemcpyHostToDevice)); }
-    PLK_HIP(hipMalloc(&s, 3 * n * 8)); PLK_HIP(hipMemcpy(s, sigma, 3 * n * 8, hipMemcpyHostToDevice));
-    PLK_HIP(hipMalloc(&t, n * 32));
-    int32_t rc = plk_quotient_dev(ctx, d[0], d[1], d[2], d[3], d[4], d[5], s, log_n, beta, gamma, t, t_len);
-    if (rc == PLK_OK && hipMemcpy(t_out_host, t, n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
-    for (int i = 0; i < 6; ++i) hipFree(d[i]);
-    hipFree(s); hipFree(t);
-    return rc;
+    DevBuf d[6], s, t;
+    for (int i = 0; i < 6; ++i) PLK_HIP(d[i].alloc_copy(src[i], n * 32));
+    PLK_HIP(s.alloc_copy(sigma, 3 * n * 8));
+    PLK_HIP(t.alloc(n * 32));
+    PLK_TRY(plk_quotient_dev(ctx, d[0].p, d[1].p, d[2].p, d[3].p, d[4].p, d[5].p, s.p, log_n, beta, gamma, t.p, t_len));
+    PLK_HIP(hipMemcpy(t_out_host, t.p, n * 32, hipMemcpyDeviceToHost));
+    return PLK_OK;
 }
 
 extern "C" int32_t plk_interpolate_permutation_dev(plk_ctx* ctx, const void* sigma_dev, uint64_t sigma_len, uint32_t log_n4, void* s_id_out_dev,
@@ -574,15 +568,14 @@ extern "C" int32_t plk_interpolate_permutation(plk_ctx* ctx, const uint64_t* sig
     if (!ctx || !s_id_out_host || !s_sigma_out_host || log_n4 < 1 || log_n4 > 27) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n4 = 1ull << log_n4;
-    void *s = nullptr, *o0, *o1;
-    if (sigma_len) { PLK_HIP(hipMalloc(&s, sigma_len * 8)); PLK_HIP(hipMemcpy(s, sigma_host, sigma_len * 8, hipMemcpyHostToDevice)); }
-    PLK_HIP(hipMalloc(&o0, n4 * 32)); PLK_HIP(hipMalloc(&o1, n4 * 32));
-    int32_t rc = plk_interpolate_permutation_dev(ctx, s, sigma_len, log_n4, o0, o1);
-    if (rc == PLK_OK && (hipMemcpy(s_id_out_host, o0, n4 * 32, hipMemcpyDeviceToHost) != hipSuccess ||
-                         hipMemcpy(s_sigma_out_host, o1, n4 * 32, hipMemcpyDeviceToHost) != hipSuccess)) rc = PLK_ERR_HIP;
-    if (s) hipFree(s);
-    hipFree(o0); hipFree(o1);
-    return rc;
+    DevBuf s, o0, o1;
+    if (sigma_len) PLK_HIP(s.alloc_copy(sigma_host, sigma_len * 8));
+    PLK_HIP(o0.alloc(n4 * 32));
+    PLK_HIP(o1.alloc(n4 * 32));
+    PLK_TRY(plk_interpolate_permutation_dev(ctx, s.p, sigma_len, log_n4, o0.p, o1.p));
+    PLK_HIP(hipMemcpy(s_id_out_host, o0.p, n4 * 32, hipMemcpyDeviceToHost));
+    PLK_HIP(hipMemcpy(s_sigma_out_host, o1.p, n4 * 32, hipMemcpyDeviceToHost));
+    return PLK_OK;
 }
 extern "C" int32_t plk_interpolate_selector(plk_ctx* ctx, const uint64_t* values_host, uint64_t len, uint64_t* coeffs_out_host, uint32_t* log_n_out) {
     if (!ctx || !values_host || !coeffs_out_host || !log_n_out || len == 0) return PLK_ERR_INVALID_ARG;
@@ -621,13 +614,14 @@ extern "C" int32_t plk_quotient_coset_dev(plk_ctx* ctx, const void* a, const voi
         args.zh_inv[i] = w8_of(host::inv(host::FR, d));
         x = host::mul(host::FR, x, w4);
     }
-    uint32_t* work = nullptr;
-    if (hipMalloc(&work, 10 * n4 * 32) != hipSuccess) { ctx->err = "out of device memory for the coset evaluations"; return PLK_ERR_ALLOC; }
+    DevBuf work_buf;
+    if (work_buf.alloc(10 * n4 * 32) != hipSuccess) { (void)hipGetLastError(); ctx->err = "out of device memory for the coset evaluations"; return PLK_ERR_ALLOC; }
+    uint32_t* work = (uint32_t*)work_buf.p;
     uint32_t* p[10];
     for (int k = 0; k < 10; ++k) p[k] = work + (size_t)k * n4 * 8;
     const void* cols[6] = {a, b, c, q_add_vals, q_mul_vals, z_vals};
     int32_t rc = PLK_OK;
-    auto fail = [&](int32_t code) { hipStreamSynchronize(st); hipFree(work); return code; };
+    auto fail = [&](int32_t code) { (void)hipStreamSynchronize(st); return code; };   // kernels may still be using the work buffer
     if (hipMemsetAsync(ctx->flag_dev, 0, 4, st) != hipSuccess) return fail(PLK_ERR_HIP);
     for (int k = 0; k < 6; ++k)
         if (hipMemcpyAsync(p[k], cols[k], n * 32, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(PLK_ERR_HIP);
@@ -652,8 +646,8 @@ extern "C" int32_t plk_quotient_coset_dev(plk_ctx* ctx, const void* a, const voi
     const uint64_t first = 3 * n >= 3 ? 3 * n - 3 : 0;
     hipLaunchKernelGGL(k_any_nonzero, dim3(64), dim3(256), 0, st, t + first * 8, (n4 - first) * 8, ctx->flag_dev);
     uint32_t flag = 0;
-    rc = read_flag(ctx, &flag);
-    hipFree(work);
+    rc = read_flag(ctx, &flag);   // waits for the stream: the work buffer is idle from here on
+    if (rc != PLK_OK) return fail(rc);
     prof_collect(ctx, false);
     PLK_TRY(rc);
     if (flag & 2u) { ctx->err = "sigma entry out of range"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
@@ -667,14 +661,12 @@ extern "C" int32_t plk_quotient_coset(plk_ctx* ctx, const uint64_t* a, const uin
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
     const uint64_t* src[6] = {a, b, c, q_add_vals, q_mul_vals, z_vals};
-    void* d[6]; void *s, *t;
-    for (int i = 0; i < 6; ++i) { PLK_HIP(hipMalloc(&d[i], n * 32)); PLK_HIP(hipMemcpy(d[i], src[i], n * 32, hipMemcpyHostToDevice)); }
-    PLK_HIP(hipMalloc(&s, 3 * n * 8)); PLK_HIP(hipMemcpy(s, sigma, 3 * n * 8, hipMemcpyHostToDevice));
-    PLK_HIP(hipMalloc(&t, 4 * n * 32));
-    int32_t rc = plk_quotient_coset_dev(ctx, d[0], d[1], d[2], d[3], d[4], d[5], s, log_n, beta, gamma, alpha, coset_gen, t);
+    DevBuf d[6], s, t;
+    for (int i = 0; i < 6; ++i) PLK_HIP(d[i].alloc_copy(src[i], n * 32));
+    PLK_HIP(s.alloc_copy(sigma, 3 * n * 8));
+    PLK_HIP(t.alloc(4 * n * 32));
+    const int32_t rc = plk_quotient_coset_dev(ctx, d[0].p, d[1].p, d[2].p, d[3].p, d[4].p, d[5].p, s.p, log_n, beta, gamma, alpha, coset_gen, t.p);
     // the coefficients are returned in both cases: a caller may want to look at a quotient that does not divide
-    if ((rc == PLK_OK || rc == PLK_ERR_NOT_DIVISIBLE) && hipMemcpy(t_out_host, t, 4 * n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = PLK_ERR_HIP;
-    for (int i = 0; i < 6; ++i) hipFree(d[i]);
-    hipFree(s); hipFree(t);
+    if (rc == PLK_OK || rc == PLK_ERR_NOT_DIVISIBLE) PLK_HIP(hipMemcpy(t_out_host, t.p, 4 * n * 32, hipMemcpyDeviceToHost));
     return rc;
 }
