@@ -164,6 +164,10 @@ int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out_xy[8], int
 int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
                            const uint64_t challenge[4], int32_t* ticket);
 int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]);
+/* Tells the library that the batch of tickets begun so far is complete.  The last stage of every MSM (bucket reduction and
+ * read-back) shares one stream; it is enqueued for the whole batch at once, ordered by expected completion, either here or at
+ * the first *_end of the batch.  Calling this right after the last *_begin lets that stage start while the host does other work. */
+int32_t plk_kzg_submit(plk_ctx* ctx);
 /* Like *_end but returns this shard's unnormalised partial (16 limbs) instead of the affine point. */
 int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]);
 

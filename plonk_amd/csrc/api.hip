@@ -260,6 +260,11 @@ extern "C" int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, ui
     *ticket = si;
     return PLK_OK;
 }
+extern "C" int32_t plk_kzg_submit(plk_ctx* ctx) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    return msm_flush_reductions(ctx);
+}
 static int32_t ticket_slot(plk_ctx* ctx, int32_t ticket, int kind, MsmSlot** out) {
     if (!ctx || ticket < 0 || ticket >= MSM_SLOTS || !ctx->slot[ticket].busy || ctx->slot[ticket].kind != kind) {
         if (ctx) ctx->err = "bad ticket";

@@ -67,6 +67,9 @@ struct MsmSlot {
     uint32_t* res_host = nullptr;      // pinned
     bool busy = false;
     int kind = 0;                      // 0 msm, 1 commit, 2 open
+    uint64_t max_entries = 0;          // of the job in flight: its accumulation time is proportional to this
+    int acc_stream = 0;                // which of the two accumulation streams runs it
+    uint32_t acc_blocks = 0;
     uint64_t host_rv[4], host_chal[4]; // opening: values finished on the host
 };
 
@@ -83,6 +86,7 @@ struct plk_ctx {
     unsigned acc_turn = 0;
     plk::MsmSlot slot[plk::MSM_SLOTS];
     int next_slot = 0;
+    std::vector<int> reduce_pending;   // slots whose sort and accumulation are enqueued but whose reduction is not yet (see msm_flush_reductions)
     // SRS
     uint64_t srs_total = 0, shard_first = 0, shard_len = 0;
     bool has_gamma = false;

@@ -8,7 +8,8 @@ namespace plk {
 // msm.hip
 int32_t msm_acquire_slot(plk_ctx* ctx, int* out);
 int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind);
-int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);
+int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);   // enqueues the pending reductions first
+int32_t msm_flush_reductions(plk_ctx* ctx);
 void slot_destroy(MsmSlot& s);
 
 // ntt.hip

@@ -468,7 +468,21 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.accumulated, st));
-    st = ctx->st_red;
+    s.max_entries = max_entries;
+    s.acc_stream = (int)((ctx->acc_turn - 1) & 1);
+    s.acc_blocks = acc_blocks;
+    ctx->reduce_pending.push_back((int)(&s - ctx->slot));
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
+// The reduction stream is a queue: a reduction that waits for a long accumulation holds up every reduction behind it, also those
+// whose accumulation finished long ago.  Reductions are therefore not enqueued with their MSM but when the first result of a
+// batch is asked for, in the order in which the accumulations are expected to finish (two streams, taken alternately, each
+// kernel's time proportional to its entries).
+static int32_t enqueue_reduction(plk_ctx* ctx, MsmSlot& s) {
+    const uint32_t acc_blocks = s.acc_blocks;
+    hipStream_t st = ctx->st_red;
     PLK_HIP(hipStreamWaitEvent(st, s.accumulated, 0));
     prof_begin(ctx, st, "msm_reduce");
     {
@@ -486,6 +500,20 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
     PLK_HIP(hipEventRecord(s.done, st));
     PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+int32_t msm_flush_reductions(plk_ctx* ctx) {
+    if (ctx->reduce_pending.empty()) return PLK_OK;
+    std::vector<std::pair<double, int>> order;
+    double stream_free[2] = {0, 0};
+    for (int si : ctx->reduce_pending) {
+        const MsmSlot& s = ctx->slot[si];
+        stream_free[s.acc_stream] += (double)s.max_entries + 65536.0;   // a launch costs something even when it is empty
+        order.push_back({stream_free[s.acc_stream], si});
+    }
+    ctx->reduce_pending.clear();
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
+    for (const auto& o : order) PLK_TRY(enqueue_reduction(ctx, ctx->slot[o.second]));
     return PLK_OK;
 }
 
@@ -508,6 +536,7 @@ void msm_host_tail(const uint32_t* marg, host::pt* out) {
 }
 
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out) {
+    PLK_TRY(msm_flush_reductions(ctx));
     PLK_HIP(hipEventSynchronize(s.done));
     msm_host_tail(s.marg_host, out);
     return PLK_OK;

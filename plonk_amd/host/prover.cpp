@@ -157,6 +157,7 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
             const int i = order[k];
             check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
         }
+        check(ctx, plk_kzg_submit(ctx));
         // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233) depend on no challenge: they are enqueued here,
         // behind the sorts, and run beside the accumulation kernels instead of on the critical path between rounds 2 and 4.
         if (in.len[0] >= n && in.len[1] >= n && in.len[2] >= n) {
@@ -188,20 +189,29 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
     for (auto& r : blind[7]) r = rng();
     int32_t z_ticket;
     check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
+    // The quotient of this constraint system has degree < n before the division by Z_H, so it is either the zero polynomial or
+    // the prover fails (:487).  Its commitment (three blinding terms, drawn here in the reference's rng order) is therefore
+    // started now, beside z's, instead of after the divisibility check; a non-zero t would simply be committed again below.
+    for (auto& r : blind[8]) r = rng();
+    int32_t t_ticket = -1;
+    check(ctx, plk_kzg_commit_begin(ctx, in.work[4], 0, &blind[8][0].v[0], &t_ticket));
+    check(ctx, plk_kzg_submit(ctx));
     lap(1);
 
     // ---- round 3: quotient t :224-259
     uint64_t t_len = 0;
-    int32_t t_ticket = -1;
     try {
         if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
             throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
         check(ctx, plk_quotient_dev(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4],
                                     &t_len));
-        for (auto& r : blind[8]) r = rng();
-        check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));
+        if (t_len != 0) {
+            finish_point(pk, t_ticket);
+            check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));
+        }
     } catch (...) {
         finish_point(pk, z_ticket);
+        finish_point(pk, t_ticket);
         throw;
     }
     comm[7].comm = finish_point(pk, z_ticket);
@@ -224,6 +234,7 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInpu
             const int i = order[k];
             check(ctx, plk_kzg_open_begin(ctx, polys[i], lens[i], &blind[i][0].v[0], zeta.v, pk.opening_challenge.v, &ticket[i]));
         }
+        check(ctx, plk_kzg_submit(ctx));
         G1Affine w9[9];
         Fr rv9[9];
         finish_points(pk, ticket, 9, true, w9, rv9, eval);
