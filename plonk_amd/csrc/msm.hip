@@ -254,35 +254,40 @@ __global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(const uint32
     if (j == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
 }
 
-// One block per output: group d of the bucket index (bits [4d, 4d+4), the last group has 3 bits) equal to v.
-constexpr int MARG_THREADS = 256;   // four waves, one per SIMD: a block fits beside the accumulation waves of a busy CU
-__global__ void __launch_bounds__(MARG_THREADS) SIDE_KERNEL_VGPRS k_msm_marginals(const uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ out) {
+// Output o of the 56 marginal sums: group d of the bucket index (bits [4d, 4d+4), the last group has 3 bits) equal to v.
+// Two kernels.  The first spreads every output over MARG_SPLIT single-wave workgroups (896 waves, about one per SIMD of the chip,
+// each adding two or four buckets per lane and folding the wave with shuffles); the second joins the MARG_SPLIT partial sums of
+// an output.  Short waves on every SIMD instead of long ones on a few: the accumulation kernel of the neighbouring MSM, whose
+// lanes all carry the same amount of work, finishes when its slowest SIMD does, and these kernels issue ahead of it.
+constexpr int MARG_SPLIT = 16;
+__device__ __forceinline__ void marginal_of(uint32_t o, uint32_t* d, uint32_t* v) { *d = o < 48 ? o >> 4 : 3; *v = o < 48 ? (o & 15) : o - 48; }
+__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(const uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part) {
     PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
-    __shared__ uint32_t part[MARG_THREADS / 64][XYZZ_WORDS];
-    const uint32_t o = blockIdx.x;
-    const uint32_t d = o < 48 ? o >> 4 : 3, v = o < 48 ? (o & 15) : o - 48;
+    const uint32_t o = blockIdx.x / MARG_SPLIT, sp = blockIdx.x % MARG_SPLIT;
+    uint32_t d, v;
+    marginal_of(o, &d, &v);
     const uint32_t shift = 4 * d, bits = d < 3 ? 4 : 3;
     const uint32_t members = MSM_BUCKETS >> bits;
     xyzz acc = xyzz_inf();
-    for (uint32_t m = threadIdx.x; m < members; m += MARG_THREADS) {
+    for (uint32_t m = sp * 64 + threadIdx.x; m < members; m += 64 * MARG_SPLIT) {
         const uint32_t idx = ((m >> shift) << (shift + bits)) | (v << shift) | (m & ((1u << shift) - 1));
         acc = xyzz_add(acc, ld_xyzz(bucket_sums + (size_t)idx * XYZZ_WORDS));
     }
     for (int s = 32; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) st_xyzz(part[wave], acc);
-    __syncthreads();
-    if (wave == 0) {
-        acc = lane < MARG_THREADS / 64 ? ld_xyzz(part[lane]) : xyzz_inf();
-        for (int s = MARG_THREADS / 128; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
-        if (lane == 0) {
-            uint32_t* dst = out + (size_t)o * 32;
-            const fe to_r = fe_const(FqP::TO_R);
-            st_fe<FqP>(dst, mul<FqP>(acc.x, to_r));
-            st_fe<FqP>(dst + 8, mul<FqP>(acc.y, to_r));
-            st_fe<FqP>(dst + 16, mul<FqP>(acc.zz, to_r));
-            st_fe<FqP>(dst + 24, mul<FqP>(acc.zzz, to_r));
-        }
+    if (threadIdx.x == 0) st_xyzz(part + (size_t)blockIdx.x * XYZZ_WORDS, acc);
+}
+__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(const uint32_t* __restrict__ part, uint32_t* __restrict__ out) {
+    PLK_SIDE_PRIO();
+    const uint32_t o = blockIdx.x, lane = threadIdx.x;
+    xyzz acc = lane < MARG_SPLIT ? ld_xyzz(part + ((size_t)o * MARG_SPLIT + lane) * XYZZ_WORDS) : xyzz_inf();
+    for (int s = MARG_SPLIT / 2; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
+    if (lane == 0) {
+        uint32_t* dst = out + (size_t)o * 32;
+        const fe to_r = fe_const(FqP::TO_R);
+        st_fe<FqP>(dst, mul<FqP>(acc.x, to_r));
+        st_fe<FqP>(dst + 8, mul<FqP>(acc.y, to_r));
+        st_fe<FqP>(dst + 16, mul<FqP>(acc.zz, to_r));
+        st_fe<FqP>(dst + 24, mul<FqP>(acc.zzz, to_r));
     }
 }
 
@@ -346,6 +351,7 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     PLK_HIP(hipMalloc(&s.bucket_sums, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
     PLK_HIP(hipMalloc(&s.flushed, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
     PLK_HIP(hipMalloc(&s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4));
+    PLK_HIP(hipMalloc(&s.marg_part, (size_t)MSM_MARGINALS * MARG_SPLIT * XYZZ_WORDS * 4));
     PLK_HIP(hipHostMalloc(&s.marg_host, (size_t)MSM_MARGINALS * 32 * 4, hipHostMallocDefault));
     PLK_HIP(hipMalloc(&s.blind_dev, 64 * 4));
     PLK_HIP(hipHostMalloc(&s.blind_host, 64 * 4, hipHostMallocDefault));
@@ -394,7 +400,7 @@ static int32_t slots_reserve(plk_ctx* ctx) {
 }
 void slot_destroy(MsmSlot& s) {
     if (!s.ready) return;
-    hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.flushed); hipFree(s.tails); hipFree(s.marg_dev);
+    hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.flushed); hipFree(s.tails); hipFree(s.marg_dev); hipFree(s.marg_part);
     hipHostFree(s.marg_host); hipFree(s.blind_dev); hipHostFree(s.blind_host); hipFree(s.scal_dev); hipFree(s.chain_dev);
     hipFree(s.res_dev); hipHostFree(s.res_host);
     hipEventDestroy(s.sorted); hipEventDestroy(s.accumulated); hipEventDestroy(s.done);
@@ -495,7 +501,8 @@ static int32_t enqueue_reduction(plk_ctx* ctx, MsmSlot& s) {
         else
             hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
     }
-    hipLaunchKernelGGL(k_msm_marginals, dim3(MSM_MARGINALS), dim3(MARG_THREADS), 0, st, s.bucket_sums, s.marg_dev);
+    hipLaunchKernelGGL(k_msm_marginals_part, dim3(MSM_MARGINALS * MARG_SPLIT), dim3(64), 0, st, s.bucket_sums, s.marg_part);
+    hipLaunchKernelGGL(k_msm_marginals_join, dim3(MSM_MARGINALS), dim3(64), 0, st, s.marg_part, s.marg_dev);
     prof_end(ctx, st);
     PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
     PLK_HIP(hipEventRecord(s.done, st));
