@@ -298,7 +298,7 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "synthetic 2^%d-gate random arithmetic circuit, BN254, hiding KZG10, full proof (BASELINE.json configs[2])" % log_n,
-                   "log_gates": log_n, "srs_points": total, "msm_pairs_per_proof": 20 * n + 45, "ntt_per_proof": 6,
+                   "log_gates": log_n, "srs_points": total, "msm_pairs_per_proof": 20 * n + 45, "ntt_per_proof": 4,
                    "parallelism": "1 GPU" if world == 1 else "MSM point-range shards x%d, partial sums all-gathered over RCCL; other rounds replicated" % world},
         "msm_gpts_per_s": round((20 * n + 45) / (ms_per_step * 1e-3) / 1e9, 4),
         "stage_ms": {k: round(float(v) / args.steps * 1e3, 3) for k, v in zip(["round1_commit", "grand_product", "quotient", "open", "assemble", "total"], stage)},
