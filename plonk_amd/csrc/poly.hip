@@ -59,34 +59,130 @@ __device__ __forceinline__ void load_quad(const uint32_t* __restrict__ c, uint64
     }
 }
 
-// S[t] = sum_{i in chunk t} c_i z^(i - t L)      (stored with bound 2)
-__global__ void __launch_bounds__(256) k_div_local(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, uint32_t* __restrict__ S) {
-    PLK_SIDE_PRIO();
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t lo = t * DIV_L;
-    if (lo >= len) return;
-    const fe z = to_rp(fe_of(zeta));
+// Three kernels whatever the length.  A workgroup of 256 threads owns DIV_BLOCK = 8192 consecutive coefficients, a thread DIV_L = 32:
+//   k_div_sums    A_b = sum_{i in block b} c_i z^(i - b E)                      (thread-local Horner, weighted tree over the block)
+//   k_div_carries C_b = A_b + z^E C_{b+1}: suffix scan over the blocks by one workgroup -> carry into every block, and h_0
+//   k_div_apply   thread-local Horner again, weighted suffix scan inside the block seeded with the block's carry, then the walk
+//                 down the thread's 32 coefficients that writes scale * h_i
+// (the coefficients are read three times, twice of them from L2; a scan with one kernel per level of a 32-ary tree took nine
+// launches at 2^20 coefficients, most of them a few microseconds of work behind 25 microseconds of launch latency).
+constexpr int DIV_THREADS = 256;
+constexpr int DIV_BLOCK = DIV_THREADS * DIV_L;
+
+// S = sum_{k < L} c_{lo + k} z^k; coefficients past len count as zero.  Result bound 3, limbs < 2^30.
+__device__ __forceinline__ fe div_local_sum(const uint32_t* __restrict__ c, uint64_t lo, uint64_t len, const fe& z) {
     fe h = fe_zero();
+    if (lo >= len) return h;
 #pragma unroll 1
     for (int q = DIV_L / 4 - 1; q >= 0; --q) {
         fe v[4];
-        load_quad(c, lo + 4 * q, len, v);     // elements past the end read as zero: they do not change the sum
+        load_quad(c, lo + 4 * q, len, v);
 #pragma unroll
         for (int k = 3; k >= 0; --k) h = add(v[k], mul<FrP>(h, z));
     }
-    st_lazy(S + 8 * t, mul<FrP>(h, fe_const(FrP::ONE)));   // back to bound 2 so that every level starts alike
+    return h;
 }
-// h_i = c_i + z h_{i+1} inside chunk t, entered with carry[t + 1] (the suffix value at the start of the next chunk).
-// hs != null: hs[i] = h_i (lazy).  q_out != null: q_out[i - 1] = scale * h_i for i >= 1.  h0_out != null: h_0, canonical.
-__global__ void __launch_bounds__(256) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry, uint64_t n_carry,
-                                                   uint32_t* __restrict__ hs, uint32_t* __restrict__ q_out, W8 scale, uint32_t* __restrict__ h0_out) {
+// V_t <- sum_{u >= t} V_u w^(u - t) over the 256 threads of the workgroup (Kogge-Stone, eight steps); w in the 2^261 form.
+// Every thread passes a normalized value; the result is normalized with bound 2.
+__device__ __forceinline__ fe div_block_suffix_scan(fe v, fe w, uint32_t* lds /* 2 x 256 x 9 words */) {
+    const uint32_t t = threadIdx.x;
+    uint32_t* cur = lds;
+    uint32_t* nxt = lds + DIV_THREADS * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cur[t * 9 + i] = v.v[i];
+    __syncthreads();
+    for (int d = 1; d < DIV_THREADS; d <<= 1) {
+        if (t + d < DIV_THREADS) {
+            fe o;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) o.v[i] = cur[(t + d) * 9 + i];
+            v = add(v, mul<FrP>(o, w));
+            norm(v);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) nxt[t * 9 + i] = v.v[i];
+        __syncthreads();
+        uint32_t* sw = cur; cur = nxt; nxt = sw;
+        w = mul<FrP>(w, w);
+    }
+    return mul<FrP>(v, fe_const(FrP::ONE));   // bound <= 3 + 2 * 8 back to 2
+}
+__device__ __forceinline__ fe div_pow2(fe x, int squarings) {
+    for (int i = 0; i < squarings; ++i) x = mul<FrP>(x, x);
+    return x;
+}
+
+__global__ void __launch_bounds__(DIV_THREADS) k_div_sums(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, uint32_t* __restrict__ A) {
     PLK_SIDE_PRIO();
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t lo = t * DIV_L;
-    if (lo >= len) return;
+    __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     const fe z = to_rp(fe_of(zeta));
-    const fe sc = q_out ? to_rp(fe_of(scale)) : fe_zero();
-    fe h = (carry && t + 1 < n_carry) ? ld_fe(carry + 8 * (t + 1)) : fe_zero();
+    fe s = div_local_sum(c, (uint64_t)blockIdx.x * DIV_BLOCK + (uint64_t)threadIdx.x * DIV_L, len, z);
+    norm(s);
+    const fe tot = div_block_suffix_scan(s, div_pow2(z, 5), lds);   // thread 0 ends up with the whole block
+    if (threadIdx.x == 0) st_lazy(A + 8ull * blockIdx.x, tot);
+}
+// carry[b] = h at the first coefficient of block b + 1 (zero for the last block); h0 = h_0, canonical.  One workgroup.
+__global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __restrict__ A, uint32_t nb, W8 zeta, uint32_t* __restrict__ carry, uint32_t* __restrict__ h0_out) {
+    PLK_SIDE_PRIO();
+    __shared__ uint32_t lds[2 * DIV_THREADS * 9];
+    __shared__ uint32_t tops[DIV_THREADS * 9];
+    const uint32_t t = threadIdx.x;
+    const uint32_t m = (nb + DIV_THREADS - 1) / DIV_THREADS;            // blocks per thread
+    const fe ze = div_pow2(to_rp(fe_of(zeta)), 13);                     // z^8192
+    // weight between the chunks of neighbouring threads: ze^m
+    fe wm = fe_const(FrP::ONE);
+    for (uint32_t k = 0; k < m; ++k) wm = mul<FrP>(wm, ze);
+    const uint32_t lo = t * m;
+    fe s = fe_zero();
+    for (uint32_t j = m; j-- > 0;) {
+        const uint32_t b = lo + j;
+        const fe a = b < nb ? ld_fe(A + 8ull * b) : fe_zero();
+        s = add(a, mul<FrP>(s, ze));
+    }
+    norm(s);
+    const fe head = div_block_suffix_scan(s, wm, lds);                  // C at the first block of this thread's chunk
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tops[t * 9 + i] = head.v[i];
+    __syncthreads();
+    fe h = fe_zero();                                                   // C at the first block of the next thread's chunk
+    if (t + 1 < DIV_THREADS) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) h.v[i] = tops[(t + 1) * 9 + i];
+    }
+    for (uint32_t j = m; j-- > 0;) {
+        const uint32_t b = lo + j;
+        if (b >= nb) continue;
+        st_lazy(carry + 8ull * b, mul<FrP>(h, fe_const(FrP::ONE)));
+        h = add(ld_fe(A + 8ull * b), mul<FrP>(h, ze));
+        norm(h);
+    }
+    if (t == 0 && h0_out) st_fe<FrP>(h0_out, mul<FrP>(h, fe_const(FrP::ONE)));
+}
+// q_out[i - 1] = scale * h_i for i >= 1
+__global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry,
+                                                           uint32_t* __restrict__ q_out, W8 scale) {
+    PLK_SIDE_PRIO();
+    __shared__ uint32_t lds[2 * DIV_THREADS * 9];
+    __shared__ uint32_t heads[DIV_THREADS * 9];
+    const uint32_t t = threadIdx.x;
+    const fe z = to_rp(fe_of(zeta));
+    const fe zl = div_pow2(z, 5);
+    const uint64_t lo = (uint64_t)blockIdx.x * DIV_BLOCK + (uint64_t)t * DIV_L;
+    const fe cin = ld_fe(carry + 8ull * blockIdx.x);
+    fe s = div_local_sum(c, lo, len, z);
+    if (t == DIV_THREADS - 1) s = add(s, mul<FrP>(cin, zl));            // h at this thread's first coefficient, given the block's carry
+    norm(s);
+    const fe head = div_block_suffix_scan(s, zl, lds);                  // h at every thread's first coefficient
+#pragma unroll
+    for (int i = 0; i < 9; ++i) heads[t * 9 + i] = head.v[i];
+    __syncthreads();
+    if (lo >= len) return;
+    fe h = cin;                                                         // h just above this thread's chunk
+    if (t + 1 < DIV_THREADS) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) h.v[i] = heads[(t + 1) * 9 + i];
+    }
+    const fe sc = to_rp(fe_of(scale));
 #pragma unroll 1
     for (int q = DIV_L / 4 - 1; q >= 0; --q) {
         fe v[4];
@@ -95,18 +191,15 @@ __global__ void __launch_bounds__(256) k_div_apply(const uint32_t* __restrict__ 
         for (int k = 3; k >= 0; --k) {
             const uint64_t i = lo + 4 * q + k;
             if (i >= len) continue;
-            h = add(v[k], mul<FrP>(h, z));      // bound 4, limbs < 2^30
-            if (hs) { fe n = h; norm(n); st_lazy(hs + 8 * i, n); }
-            if (q_out && i >= 1) st_fe<FrP>(q_out + 8 * (i - 1), mul<FrP>(h, sc));
-            if (h0_out && i == 0) st_fe<FrP>(h0_out, mul<FrP>(h, fe_const(FrP::ONE)));
+            h = add(v[k], mul<FrP>(h, z));      // bound 3, limbs < 2^30
+            if (i >= 1) st_fe<FrP>(q_out + 8 * (i - 1), mul<FrP>(h, sc));
         }
     }
 }
 
 uint64_t division_work_words(uint64_t len) {
-    uint64_t words = 8, l = len;
-    while (l > 1) { l = (l + DIV_L - 1) / DIV_L; words += 2 * l * 8; }
-    return words + 64;
+    const uint64_t nb = (len + DIV_BLOCK - 1) / DIV_BLOCK;
+    return 2 * (nb + 1) * 8 + 64;
 }
 int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
                          uint32_t* q_out, uint32_t* h0_out, uint32_t* work) {
@@ -114,30 +207,14 @@ int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, u
         if (h0_out) PLK_HIP(hipMemsetAsync(h0_out, 0, 32, st));
         return PLK_OK;
     }
-    // level k works at the point zeta^(L^k)
-    std::vector<uint64_t> lens{len};
-    while (lens.back() > 1) lens.push_back((lens.back() + DIV_L - 1) / DIV_L);
-    const int levels = (int)lens.size();           // arrays 0 .. levels-1, the last has one element
-    std::vector<host::el> zp(levels);
-    zp[0] = host::el_load(zeta);
-    for (int k = 1; k < levels; ++k) { host::el z = zp[k - 1]; for (int s = 0; s < 5; ++s) z = host::mul(host::FR, z, z); zp[k] = z; }
-    std::vector<uint32_t*> S(levels, nullptr), HS(levels, nullptr);
-    S[0] = const_cast<uint32_t*>(coeffs);
-    uint32_t* w = work;
-    for (int k = 1; k < levels; ++k) { S[k] = w; w += lens[k] * 8; HS[k] = w; w += lens[k] * 8; }
-    const W8 sc = w8_of(scale ? scale : host::FR.one);
+    const uint32_t nb = (uint32_t)((len + DIV_BLOCK - 1) / DIV_BLOCK);
+    uint32_t* A = work;
+    uint32_t* carry = work + (size_t)(nb + 1) * 8;
+    const W8 z = w8_of(zeta);
     prof_begin(ctx, st, "division");
-    for (int k = 0; k + 1 < levels; ++k) {
-        const uint64_t nthr = lens[k + 1];
-        hipLaunchKernelGGL(k_div_local, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, S[k], lens[k], w8_of(zp[k]), S[k + 1]);
-    }
-    for (int k = levels - 1; k >= 0; --k) {
-        const uint64_t nthr = (lens[k] + DIV_L - 1) / DIV_L;
-        const bool top = k + 1 >= levels;
-        hipLaunchKernelGGL(k_div_apply, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, S[k], lens[k], w8_of(zp[k]),
-                           top ? (const uint32_t*)nullptr : HS[k + 1], top ? 0 : lens[k + 1],
-                           k == 0 ? (uint32_t*)nullptr : HS[k], k == 0 ? q_out : (uint32_t*)nullptr, sc, k == 0 ? h0_out : (uint32_t*)nullptr);
-    }
+    hipLaunchKernelGGL(k_div_sums, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, A);
+    hipLaunchKernelGGL(k_div_carries, dim3(1), dim3(DIV_THREADS), 0, st, A, nb, z, carry, h0_out);
+    if (q_out && len > 1) hipLaunchKernelGGL(k_div_apply, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, w8_of(scale ? scale : host::FR.one));
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
