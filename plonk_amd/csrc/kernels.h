@@ -18,10 +18,11 @@ int32_t ntt_twiddles(plk_ctx* ctx, uint32_t log_n, const uint32_t** out);   // w
 void ntt_release(plk_ctx* ctx);
 
 // poly.hip
-// Suffix Horner scan on stream st:  h_i = sum_{k>=i} c_k zeta^(k-i).  Writes scale*h_i for i = 1..len-1 to q_out[i-1]
-// (skipped when q_out is null) and h_0 (unscaled) to h0_out (8 words, canonical).  work: >= division_work_words(len) words.
+// Suffix Horner scan on stream st:  h_i = sum_{k>=i} c_k zeta^(k-i).  Writes scale*h_i to q_out[i-1] for the quotient indices
+// i-1 in [q_first, q_first + q_count) (nothing when q_out is null; a sharded context only needs its own range) and h_0 (unscaled)
+// to h0_out (8 words, canonical).  work: >= division_work_words(len) words.
 int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs_dev, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
-                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work);
+                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work, uint64_t q_first, uint64_t q_count);
 uint64_t division_work_words(uint64_t len);
 
 }  // namespace plk

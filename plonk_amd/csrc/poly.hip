@@ -6,6 +6,7 @@
 #include "common.cuh"
 #include "host_math.hpp"
 #include "kernels.h"
+#include <algorithm>
 
 namespace plk {
 
@@ -160,15 +161,15 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __r
 }
 // q_out[i - 1] = scale * h_i for i >= 1
 __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry,
-                                                           uint32_t* __restrict__ q_out, W8 scale) {
+                                                           uint32_t* __restrict__ q_out, W8 scale, uint32_t first_block) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     __shared__ uint32_t heads[DIV_THREADS * 9];
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, blk = first_block + blockIdx.x;
     const fe z = to_rp(fe_of(zeta));
     const fe zl = div_pow2(z, 5);
-    const uint64_t lo = (uint64_t)blockIdx.x * DIV_BLOCK + (uint64_t)t * DIV_L;
-    const fe cin = ld_fe(carry + 8ull * blockIdx.x);
+    const uint64_t lo = (uint64_t)blk * DIV_BLOCK + (uint64_t)t * DIV_L;
+    const fe cin = ld_fe(carry + 8ull * blk);
     fe s = div_local_sum(c, lo, len, z);
     if (t == DIV_THREADS - 1) s = add(s, mul<FrP>(cin, zl));            // h at this thread's first coefficient, given the block's carry
     norm(s);
@@ -202,7 +203,7 @@ uint64_t division_work_words(uint64_t len) {
     return 2 * (nb + 1) * 8 + 64;
 }
 int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
-                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work) {
+                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work, uint64_t q_first, uint64_t q_count) {
     if (len == 0) {
         if (h0_out) PLK_HIP(hipMemsetAsync(h0_out, 0, 32, st));
         return PLK_OK;
@@ -214,7 +215,14 @@ int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, u
     prof_begin(ctx, st, "division");
     hipLaunchKernelGGL(k_div_sums, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, A);
     hipLaunchKernelGGL(k_div_carries, dim3(1), dim3(DIV_THREADS), 0, st, A, nb, z, carry, h0_out);
-    if (q_out && len > 1) hipLaunchKernelGGL(k_div_apply, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, w8_of(scale ? scale : host::FR.one));
+    if (q_out && len > 1 && q_count > 0) {
+        // q_out[k] comes from coefficient k + 1: only the blocks that hold coefficients q_first + 1 .. q_first + q_count are walked
+        const uint64_t hi = std::min<uint64_t>(q_first + q_count, len - 1);
+        if (q_first < hi) {
+            const uint32_t b0 = (uint32_t)((q_first + 1) / DIV_BLOCK), b1 = (uint32_t)(hi / DIV_BLOCK);
+            hipLaunchKernelGGL(k_div_apply, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, w8_of(scale ? scale : host::FR.one), b0);
+        }
+    }
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
@@ -495,7 +503,7 @@ extern "C" int32_t plk_poly_eval_dev(plk_ctx* ctx, const void* coeffs_dev, uint6
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t words = division_work_words(len);
     PLK_TRY(ensure_scratch(ctx, words * 4));
-    PLK_TRY(division_enqueue(ctx, ctx->stream, (const uint32_t*)coeffs_dev, len, x, nullptr, nullptr, ctx->scratch, ctx->scratch + 8));
+    PLK_TRY(division_enqueue(ctx, ctx->stream, (const uint32_t*)coeffs_dev, len, x, nullptr, nullptr, ctx->scratch, ctx->scratch + 8, 0, 0));
     PLK_HIP(hipMemcpyAsync(out, ctx->scratch, 32, hipMemcpyDeviceToHost, ctx->stream));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx, false);

@@ -223,6 +223,13 @@ class Context:
     def grand_product_dev(self, d_w, d_sigma, log_n, beta, gamma, d_out):
         self._ck(self.lib.plk_grand_product_dev(self.h, _vp(d_w), _vp(d_sigma), C.c_uint32(log_n), _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))), _vp(d_out)))
 
+    def grand_product_values_dev(self, d_w, d_sigma, log_n, beta, gamma, d_vals, d_out):
+        self._ck(self.lib.plk_grand_product_values_dev(self.h, _vp(d_w), _vp(d_sigma), C.c_uint32(log_n), _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))),
+                                                       _vp(d_vals), _vp(d_out)))
+
+    def submit(self):
+        self._ck(self.lib.plk_kzg_submit(self.h))
+
     def quotient(self, a, b, c, qa, qm, zv, sigma, beta, gamma):
         a = _fr(a); n = len(a); log_n = (n - 1).bit_length()
         out = np.empty((n, 4), dtype=np.uint64); tlen = C.c_uint64(0)

@@ -135,6 +135,33 @@ def test_grand_product_and_quotient(ctx, orc, log_n):
     assert orc.quotient(a, b, bad, qa, qm, zv, sigma, beta, gamma) == 1
 
 
+def test_grand_product_values_and_ticket_batches(ctx, orc, srs):
+    """plk_grand_product_values_dev hands out z on H beside the coefficients; tickets of one batch may be ended in any order,
+    with or without plk_kzg_submit."""
+    inp = _circuit(orc, 6, 17)
+    n = inp["n"]
+    w = orc.fr_from_ints(inp["witness_flat"]); sigma = np.array(inp["sigma"], dtype=np.uint64)
+    beta, gamma = rand_fr(orc, 2, 5)
+    zv, zc = orc.grand_product(w, sigma, beta, gamma)
+    d_w, d_s = ctx.upload(w), ctx.upload(sigma)
+    d_v, d_c = ctx.malloc(n * 32), ctx.malloc(n * 32)
+    ctx.grand_product_values_dev(d_w, d_s, 6, beta, gamma, d_v, d_c)
+    assert np.array_equal(ctx.download(d_v, (n, 4)), zv) and np.array_equal(ctx.download(d_c, (n, 4)), zc)
+    polys = [rand_fr(orc, k, 900 + k) for k in (64, 0, 1, 4096, 100)]
+    blinds = [rand_fr(orc, 3, 950 + i) for i in range(len(polys))]
+    want = [orc.kzg_commit(srs["g"], srs["gg"], p, b) for p, b in zip(polys, blinds)]
+    dev = [ctx.upload(p) for p in polys]
+    for use_submit in (False, True):
+        tickets = [ctx.commit_begin(d, len(p), b) for d, p, b in zip(dev, polys, blinds)]
+        if use_submit:
+            ctx.submit()
+        for i in (3, 0, 4, 1, 2):
+            got, inf = ctx.commit_end(tickets[i])
+            assert inf == want[i][1] and np.array_equal(got, want[i][0])
+    for d in dev + [d_w, d_s, d_v, d_c]:
+        ctx.free(d)
+
+
 @pytest.mark.parametrize("log_n,coset", [(0, None), (1, None), (2, None), (3, 7), (5, None), (9, None), (12, 7)])
 def test_quotient_on_the_extended_coset(ctx, orc, log_n, coset):
     """plk_quotient_coset against the oracle, which divides in coefficient form and never touches a coset."""
