@@ -199,10 +199,10 @@ def main():
     pk = ProverKey(local_rank)
     tau, gscal = synth.seeded_scalars(2, 7)
     total = n4 + 1
-    per = (total + world - 1) // world
-    first = rank * per
-    count = max(0, min(per, total - first))
-    pk.generate_srs(tau, gscal, total, shard_first=first, shard_len=count)
+    # block-cyclic point ranges (blocks of 4096 powers dealt to the ranks in turn): every MSM of the proof, the n-coefficient ones
+    # and the 4n-coefficient one alike, is split evenly; contiguous ranges of the 4n + 1 powers would leave the first ranks
+    # with all of the n-coefficient polynomials
+    pk.generate_srs_cyclic(tau, gscal, total, rank, world, log_block=12)
     if world > 1:
         bufs = {}
 
@@ -274,7 +274,7 @@ def main():
     pk.ctx.free(d_iso)
     iso_ms, iso_n = pk.ctx.profile_get("msm_accumulate")
     iso_launch_ms = iso_ms / max(1, iso_n)
-    iso_pairs = max(0, min(first + count, len(iso_poly)) - first) + (3 if rank == 0 else 0)
+    iso_pairs = len(iso_poly) // world + (3 if rank == 0 else 0)
     achieved_iso = iso_pairs * mads_per_pair / (iso_launch_ms * 1e-3) if iso_launch_ms > 0 else 0.0
     pk.ctx.profile_enable(False)
     bytes_per_launch = pairs_per_launch * 96.0
@@ -299,7 +299,7 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "synthetic 2^%d-gate random arithmetic circuit, BN254, hiding KZG10, full proof (BASELINE.json configs[2])" % log_n,
                    "log_gates": log_n, "srs_points": total, "msm_pairs_per_proof": 20 * n + 45, "ntt_per_proof": 4,
-                   "parallelism": "1 GPU" if world == 1 else "MSM point-range shards x%d, partial sums all-gathered over RCCL; other rounds replicated" % world},
+                   "parallelism": "1 GPU" if world == 1 else "MSM sharded over %d GPUs by block-cyclic point ranges (4096 points per block), partial sums all-gathered over RCCL; other rounds replicated" % world},
         "msm_gpts_per_s": round((20 * n + 45) / (ms_per_step * 1e-3) / 1e9, 4),
         "stage_ms": {k: round(float(v) / args.steps * 1e3, 3) for k, v in zip(["round1_commit", "grand_product", "quotient", "open", "assemble", "total"], stage)},
         "kernel_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},

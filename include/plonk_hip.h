@@ -61,6 +61,14 @@ int32_t plk_srs_load_shard(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t sha
 int32_t plk_srs_generate(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t len);
 int32_t plk_srs_generate_shard(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t shard_first,
                                uint64_t shard_len, uint64_t total_len);
+/* Block-cyclic shards: the powers are cut into blocks of 2^log_block points and block b belongs to rank b mod world, so that every
+ * MSM, whatever its length, is spread evenly over the ranks (with contiguous ranges of a 4n-point SRS the n-coefficient polynomials
+ * of the prover would all land on the first ranks).  plk_srs_load_cyclic takes the whole array of powers and keeps this rank's blocks.
+ * Everything else is as for contiguous shards: MSMs return this rank's partial sum, the gamma powers live on rank 0. */
+int32_t plk_srs_generate_cyclic(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint32_t rank, uint32_t world,
+                                uint32_t log_block, uint64_t total_len);
+int32_t plk_srs_load_cyclic(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t total_len, const uint64_t* gamma_g_xy_host, uint32_t rank,
+                            uint32_t world, uint32_t log_block);
 /* Reads points back: which = 0 powers_of_g (global index first..first+count), 1 powers_of_gamma_g. */
 int32_t plk_srs_read(plk_ctx* ctx, int32_t which, uint64_t first, uint64_t count, uint64_t* out_xy_host);
 

@@ -311,8 +311,10 @@ extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint
     PLK_TRY(grow(ctx, ctx->st_sort, &s.chain_dev, &s.chain_cap, division_work_words(len)));
     PLK_TRY(sort_after_compute(ctx));
     // witness polynomial of challenge*f: scalars challenge * h_i, i >= 1; h_0 = f(zeta)
-    PLK_TRY(division_enqueue(ctx, ctx->st_sort, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev, ctx->shard_first,
-                             ctx->shard_len));
+    // a contiguous shard needs its own range of quotient coefficients only, a block-cyclic one has a part in every stretch
+    const bool cyclic = ctx->cyc_world > 1;
+    PLK_TRY(division_enqueue(ctx, ctx->st_sort, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev,
+                             cyclic ? 0 : ctx->shard_first, cyclic ? len : ctx->shard_len));
     PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, ctx->st_sort));
     // hiding part on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2, random_v = r'(zeta)
     using namespace host;

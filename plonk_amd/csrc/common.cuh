@@ -23,9 +23,14 @@ constexpr int MSM_MARGINALS = 56;       // 16 + 16 + 16 + 8 partial sums handed 
 constexpr int XYZZ_WORDS = 36;          // unnormalised point in device scratch: 4 coordinates x 9 limbs
 
 struct MsmSeg {
-    const uint32_t* scalars;   // count Fr elements, 8 words each, x*2^256 form
+    const uint32_t* scalars;   // Fr elements, 8 words each, x*2^256 form: entry idx of the segment reads scalars[8 * scalar_index(idx)]
     uint32_t count;
-    uint32_t table_off;        // index of the first base inside a window table
+    uint32_t table_off;        // index of the first base inside a window table; entry idx uses base table_off + idx
+    // Block-cyclic shards (world > 1): the context holds the blocks of 2^log_block consecutive SRS points whose number is
+    // congruent to rank modulo world, packed in order; `scalars` then points at the scalar of global point `origin`, and entry idx
+    // belongs to global point ((t >> log_block) * world + rank) << log_block | (t & (2^log_block - 1)),  t = table_off + idx.
+    uint32_t world, rank, log_block;
+    uint64_t origin;
 };
 struct MsmSegs {
     MsmSeg s[2];
@@ -90,6 +95,7 @@ struct plk_ctx {
     std::vector<int> reduce_pending;   // slots whose sort and accumulation are enqueued but whose reduction is not yet (see msm_flush_reductions)
     // SRS
     uint64_t srs_total = 0, shard_first = 0, shard_len = 0;
+    uint32_t cyc_world = 1, cyc_rank = 0, cyc_log_block = 0;   // cyc_world > 1: block-cyclic shard (shard_first unused, shard_len = points held)
     bool has_gamma = false;
     uint64_t table_stride = 0;         // points per window table: shard_len + 3 (gamma powers at the end)
     uint32_t* tables = nullptr;        // [MSM_WINDOWS][table_stride] affine, 16 words each, x*2^261 form

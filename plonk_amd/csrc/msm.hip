@@ -39,7 +39,13 @@ __device__ __forceinline__ void scalar_digits(const uint32_t* sp, int32_t* d) {
 }
 __device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint32_t idx, uint32_t* table_index) {
     if (idx < segs.s[0].count) {
-        *table_index = segs.s[0].table_off + idx;
+        const uint32_t t = segs.s[0].table_off + idx;
+        *table_index = t;
+        if (segs.s[0].world > 1) {
+            const uint32_t lb = segs.s[0].log_block;
+            const uint64_t global = ((((uint64_t)(t >> lb)) * segs.s[0].world + segs.s[0].rank) << lb) | (t & ((1u << lb) - 1));
+            return segs.s[0].scalars + 8ull * (global - segs.s[0].origin);
+        }
         return segs.s[0].scalars + 8ull * idx;
     }
     idx -= segs.s[0].count;
@@ -319,12 +325,13 @@ __global__ void __launch_bounds__(256) k_table_next(const uint32_t* __restrict__
 // dst[i] = scale * tau^(first + i) * G through 8-bit fixed-base windows of G: gt[w][d] = d * 2^(8 w) * G.
 // tau_pow2[k] = tau^(2^k), scale: x*2^256 words.
 __global__ void __launch_bounds__(256) k_srs_generate(const uint32_t* __restrict__ gt, const uint32_t* __restrict__ tau_pow2, const uint32_t* __restrict__ scale,
-                                                      uint64_t first, uint64_t count, uint32_t* __restrict__ dst) {
+                                                      uint64_t first, uint64_t count, uint32_t* __restrict__ dst, uint32_t world, uint32_t rank, uint32_t log_block) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     const fe to_rp = fe_const(FrP::TO_RP);
     fe s = ld_fe(scale);
-    const uint64_t e = first + i;
+    // power of tau of local point i: contiguous shards start at `first`, block-cyclic ones own every world-th block
+    const uint64_t e = world > 1 ? (((i >> log_block) * world + rank) << log_block | (i & ((1ull << log_block) - 1))) : first + i;
     for (int k = 0; k < 40; ++k)
         if ((e >> k) & 1) s = mul<FrP>(s, mul<FrP>(ld_fe(tau_pow2 + 8 * k), to_rp));
     uint32_t w[8];
@@ -421,8 +428,23 @@ int32_t msm_acquire_slot(plk_ctx* ctx, int* out) {
     return PLK_ERR_INVALID_ARG;
 }
 
+// Number of SRS points with global index < x that a block-cyclic shard holds (they are packed in index order).
+static uint64_t cyclic_owned_below(uint32_t world, uint32_t rank, uint32_t log_block, uint64_t x) {
+    const uint64_t B = 1ull << log_block, blk = x >> log_block, rem = x & (B - 1);
+    const uint64_t cycles = blk / world, pos = blk % world;
+    return cycles * B + (pos > rank ? B : (pos == rank ? rem : 0));
+}
 // Restricts the global range [base_offset, base_offset + k) to this context's shard.
 static void clip_to_shard(const plk_ctx* ctx, const uint32_t* scalars, uint64_t k, uint64_t base_offset, MsmSeg* seg) {
+    seg->world = 1; seg->rank = 0; seg->log_block = 0; seg->origin = 0;
+    if (ctx->cyc_world > 1) {
+        const uint64_t t_lo = cyclic_owned_below(ctx->cyc_world, ctx->cyc_rank, ctx->cyc_log_block, base_offset);
+        const uint64_t t_hi = cyclic_owned_below(ctx->cyc_world, ctx->cyc_rank, ctx->cyc_log_block, base_offset + k);
+        seg->scalars = scalars; seg->origin = base_offset;
+        seg->count = (uint32_t)(t_hi - t_lo); seg->table_off = (uint32_t)t_lo;
+        seg->world = ctx->cyc_world; seg->rank = ctx->cyc_rank; seg->log_block = ctx->cyc_log_block;
+        return;
+    }
     uint64_t lo = base_offset, hi = base_offset + k;
     const uint64_t slo = ctx->shard_first, shi = ctx->shard_first + ctx->shard_len;
     if (lo < slo) lo = slo;
@@ -443,6 +465,7 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     segs.s[1].scalars = s.blind_dev;
     segs.s[1].count = ctx->has_gamma ? n_blind : 0;
     segs.s[1].table_off = (uint32_t)ctx->shard_len;
+    segs.s[1].world = 1; segs.s[1].rank = 0; segs.s[1].log_block = 0; segs.s[1].origin = 0;
     segs.nseg = 2;
     segs.total = segs.s[0].count + segs.s[1].count;
     const uint64_t max_entries = (uint64_t)segs.total * MSM_WINDOWS;
@@ -554,15 +577,30 @@ static int32_t srs_alloc(plk_ctx* ctx, uint64_t shard_first, uint64_t shard_len,
     if (shard_first + shard_len > total_len || shard_len == 0 || shard_len + 3 >= (1ull << 27)) { ctx->err = "bad SRS shard"; return PLK_ERR_INVALID_ARG; }
     if (ctx->tables) { PLK_HIP(hipDeviceSynchronize()); PLK_HIP(hipFree(ctx->tables)); ctx->tables = nullptr; }
     ctx->srs_total = total_len; ctx->shard_first = shard_first; ctx->shard_len = shard_len;
+    ctx->cyc_world = 1; ctx->cyc_rank = 0; ctx->cyc_log_block = 0;
     ctx->has_gamma = shard_first == 0;
     ctx->table_stride = shard_len + 3;
     PLK_HIP(hipMalloc(&ctx->tables, (size_t)MSM_WINDOWS * ctx->table_stride * 64));
     if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(ctx->tables + 16 * shard_len, 0, 3 * 64, ctx->stream));
     return PLK_OK;
 }
+// Block-cyclic shard: blocks of 2^log_block points, block b belongs to rank b mod world.
+static int32_t srs_alloc_cyclic(plk_ctx* ctx, uint32_t rank, uint32_t world, uint32_t log_block, uint64_t total_len) {
+    if (world == 0 || rank >= world || log_block > 24 || total_len == 0) { ctx->err = "bad cyclic shard"; return PLK_ERR_INVALID_ARG; }
+    if (world == 1) return srs_alloc(ctx, 0, total_len, total_len);
+    const uint64_t held = cyclic_owned_below(world, rank, log_block, total_len);
+    // a rank may hold nothing of a very short SRS; it still needs a (one-point) table so that every launch has valid operands
+    PLK_TRY(srs_alloc(ctx, 0, held ? held : 1, total_len + (held ? 0 : 1)));
+    ctx->srs_total = total_len;
+    ctx->shard_len = held;
+    ctx->cyc_world = world; ctx->cyc_rank = rank; ctx->cyc_log_block = log_block;
+    ctx->has_gamma = rank == 0;
+    if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(ctx->tables + 16 * ctx->shard_len, 0, 3 * 64, ctx->stream));
+    return PLK_OK;
+}
 static int32_t srs_build_tables(plk_ctx* ctx) {
-    const uint64_t cnt = ctx->has_gamma ? ctx->table_stride : ctx->shard_len;
-    for (int j = 1; j < MSM_WINDOWS; ++j) {
+    const uint64_t cnt = ctx->has_gamma ? ctx->shard_len + 3 : ctx->shard_len;   // a cyclic shard of a short SRS may hold no point at all
+    for (int j = 1; j < MSM_WINDOWS && cnt > 0; ++j) {
         const uint32_t* prev = ctx->tables + (size_t)(j - 1) * ctx->table_stride * 16;
         uint32_t* next = ctx->tables + (size_t)j * ctx->table_stride * 16;
         hipLaunchKernelGGL(k_table_next, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, cnt);
@@ -596,11 +634,9 @@ extern "C" int32_t plk_srs_load(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_
     return plk_srs_load_shard(ctx, g_xy_host, 0, len, len, gamma_g_xy_host);
 }
 
-extern "C" int32_t plk_srs_generate_shard(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t shard_first, uint64_t shard_len,
-                                          uint64_t total_len) {
-    if (!ctx || !tau || !gscal) return PLK_ERR_INVALID_ARG;
-    PLK_HIP(hipSetDevice(ctx->device));
-    PLK_TRY(srs_alloc(ctx, shard_first, shard_len, total_len));
+// fills the tables of the shard that srs_alloc / srs_alloc_cyclic described
+static int32_t srs_generate_points(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4]) {
+    const uint64_t shard_first = ctx->shard_first, shard_len = ctx->shard_len;
     using namespace host;
     // fixed-base table of the generator: gt[w][d] = d * 2^(8w) * G, affine, x*2^256 form on the host
     std::vector<uint64_t> gt((size_t)32 * 256 * 8, 0);
@@ -636,12 +672,51 @@ extern "C" int32_t plk_srs_generate_shard(plk_ctx* ctx, const uint64_t tau[4], c
     memcpy(sc, FR.one, 32); memcpy(sc + 4, gscal, 32);
     PLK_HIP(hipMemcpy(sc_dev, sc, 64, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fq_to_rp, dim3(32 * 256 * 2 / 256), dim3(256), 0, ctx->stream, gt_dev, gt_rp, (uint64_t)32 * 256 * 2);
-    hipLaunchKernelGGL(k_srs_generate, dim3((unsigned)((shard_len + 255) / 256)), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev, shard_first, shard_len, ctx->tables);
+    if (shard_len)
+        hipLaunchKernelGGL(k_srs_generate, dim3((unsigned)((shard_len + 255) / 256)), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev, shard_first, shard_len, ctx->tables,
+                           ctx->cyc_world, ctx->cyc_rank, ctx->cyc_log_block);
     if (ctx->has_gamma)
-        hipLaunchKernelGGL(k_srs_generate, dim3(1), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev + 8, (uint64_t)0, (uint64_t)3, ctx->tables + 16 * shard_len);
+        hipLaunchKernelGGL(k_srs_generate, dim3(1), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev + 8, (uint64_t)0, (uint64_t)3, ctx->tables + 16 * shard_len, 1u, 0u, 0u);
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     hipFree(gt_dev); hipFree(gt_rp); hipFree(tp_dev); hipFree(sc_dev);
+    return srs_build_tables(ctx);
+}
+extern "C" int32_t plk_srs_generate_shard(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t shard_first, uint64_t shard_len,
+                                          uint64_t total_len) {
+    if (!ctx || !tau || !gscal) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(srs_alloc(ctx, shard_first, shard_len, total_len));
+    return srs_generate_points(ctx, tau, gscal);
+}
+extern "C" int32_t plk_srs_generate_cyclic(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint32_t rank, uint32_t world, uint32_t log_block,
+                                           uint64_t total_len) {
+    if (!ctx || !tau || !gscal) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(srs_alloc_cyclic(ctx, rank, world, log_block, total_len));
+    return srs_generate_points(ctx, tau, gscal);
+}
+extern "C" int32_t plk_srs_load_cyclic(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t total_len, const uint64_t* gamma_g_xy_host, uint32_t rank, uint32_t world,
+                                       uint32_t log_block) {
+    if (!ctx || !g_xy_host) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (world <= 1) return plk_srs_load_shard(ctx, g_xy_host, 0, total_len, total_len, gamma_g_xy_host);
+    PLK_TRY(srs_alloc_cyclic(ctx, rank, world, log_block, total_len));
+    if (ctx->has_gamma && !gamma_g_xy_host) { ctx->err = "rank 0 needs the gamma powers"; return PLK_ERR_INVALID_ARG; }
+    const uint64_t cnt = ctx->shard_len + (ctx->has_gamma ? 3 : 0);
+    DevBuf staging_buf;
+    PLK_HIP(staging_buf.alloc(cnt * 64));
+    uint32_t* staging = (uint32_t*)staging_buf.p;
+    const uint64_t B = 1ull << log_block;
+    uint64_t local = 0;
+    for (uint64_t blk = rank; (blk << log_block) < total_len; blk += world) {   // this rank's blocks, in index order
+        const uint64_t first = blk << log_block, len = std::min(B, total_len - first);
+        PLK_HIP(hipMemcpyAsync(staging + 16 * local, g_xy_host + 8 * first, len * 64, hipMemcpyHostToDevice, ctx->stream));
+        local += len;
+    }
+    if (ctx->has_gamma) PLK_HIP(hipMemcpyAsync(staging + 16 * ctx->shard_len, gamma_g_xy_host, 3 * 64, hipMemcpyHostToDevice, ctx->stream));
+    if (cnt) hipLaunchKernelGGL(k_fq_to_rp, dim3((unsigned)((cnt * 2 + 255) / 256)), dim3(256), 0, ctx->stream, staging, ctx->tables, cnt * 2);
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
     return srs_build_tables(ctx);
 }
 extern "C" int32_t plk_srs_generate(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t len) {
@@ -652,7 +727,14 @@ extern "C" int32_t plk_srs_read(plk_ctx* ctx, int32_t which, uint64_t first, uin
     if (!ctx || !ctx->tables || !out_xy_host) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     uint64_t off;
-    if (which == 0) {
+    if (which == 0 && ctx->cyc_world > 1) {
+        // a range inside one block that this rank holds
+        const uint64_t B = 1ull << ctx->cyc_log_block;
+        if (count == 0 || (first >> ctx->cyc_log_block) % ctx->cyc_world != ctx->cyc_rank || (first & (B - 1)) + count > B || first + count > ctx->srs_total) {
+            ctx->err = "range outside one block of this cyclic shard"; return PLK_ERR_INVALID_ARG;
+        }
+        off = cyclic_owned_below(ctx->cyc_world, ctx->cyc_rank, ctx->cyc_log_block, first);
+    } else if (which == 0) {
         if (first < ctx->shard_first || first + count > ctx->shard_first + ctx->shard_len) { ctx->err = "range outside this shard"; return PLK_ERR_INVALID_ARG; }
         off = first - ctx->shard_first;
     } else {

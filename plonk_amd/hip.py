@@ -20,7 +20,7 @@ STATUS = {
 # every symbol include/plonk_hip.h declares
 EXPORTS = [
     "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync", "plk_copy_dev",
-    "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_read",
+    "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_generate_cyclic", "plk_srs_load_cyclic", "plk_srs_read",
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
@@ -142,6 +142,15 @@ class Context:
         sl = length if shard_len is None else shard_len
         self._ck(self.lib.plk_srs_generate_shard(self.h, _ptr(_fr(tau, (4,))), _ptr(_fr(gscal, (4,))), C.c_uint64(shard_first), C.c_uint64(sl),
                                                  C.c_uint64(length)))
+
+    def srs_generate_cyclic(self, tau, gscal, length, rank, world, log_block=12):
+        self._ck(self.lib.plk_srs_generate_cyclic(self.h, _ptr(_fr(tau, (4,))), _ptr(_fr(gscal, (4,))), C.c_uint32(rank), C.c_uint32(world),
+                                                  C.c_uint32(log_block), C.c_uint64(length)))
+
+    def srs_load_cyclic(self, g_xy, gamma_g_xy, rank, world, log_block=12):
+        g = _fr(g_xy, (-1, 8))
+        gg = _fr(gamma_g_xy, (-1, 8)) if gamma_g_xy is not None else None
+        self._ck(self.lib.plk_srs_load_cyclic(self.h, _ptr(g), C.c_uint64(len(g)), _ptr(gg), C.c_uint32(rank), C.c_uint32(world), C.c_uint32(log_block)))
 
     def srs_read(self, which, first, count):
         out = np.empty((count, 8), dtype=np.uint64)

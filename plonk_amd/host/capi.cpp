@@ -33,6 +33,9 @@ int32_t plonk_pk_load(void* pk, const uint64_t* g_xy, uint64_t len, const uint64
 int32_t plonk_pk_generate(void* pk, const uint64_t* tau, const uint64_t* gscal, uint64_t first, uint64_t count, uint64_t len) {
     return guarded([&] { Fr t, g; memcpy(t.v, tau, 32); memcpy(g.v, gscal, 32); static_cast<KZGProverKey*>(pk)->generate_shard(t, g, first, count, len); });
 }
+int32_t plonk_pk_generate_cyclic(void* pk, const uint64_t* tau, const uint64_t* gscal, uint32_t rank, uint32_t world, uint32_t log_block, uint64_t len) {
+    return guarded([&] { Fr t, g; memcpy(t.v, tau, 32); memcpy(g.v, gscal, 32); static_cast<KZGProverKey*>(pk)->generate_cyclic(t, g, rank, world, log_block, len); });
+}
 int32_t plonk_pk_set_opening_challenge(void* pk, const uint64_t* c) { return guarded([&] { memcpy(static_cast<KZGProverKey*>(pk)->opening_challenge.v, c, 32); }); }
 // gather(user, mine[count][16], count, all[world][count][16])
 typedef void (*plonk_gather_fn)(void* user, const uint64_t* mine, uint64_t count, uint64_t* all);

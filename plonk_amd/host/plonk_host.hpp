@@ -88,6 +88,10 @@ public:
     void generate(const Fr& tau, const Fr& gscal, uint64_t len);
     // this rank keeps powers [first, first + count) of a total of len
     void generate_shard(const Fr& tau, const Fr& gscal, uint64_t first, uint64_t count, uint64_t len);
+    // this rank keeps every world_size-th block of 2^log_block powers (block b belongs to rank b mod world_size): unlike contiguous
+    // ranges this spreads the prover's n-coefficient polynomials over all ranks although the SRS has 4n + 1 powers
+    void generate_cyclic(const Fr& tau, const Fr& gscal, uint32_t rank, uint32_t world_size, uint32_t log_block, uint64_t len);
+    void load_cyclic(const uint64_t* g_xy, uint64_t len, const uint64_t* gamma_g_xy, uint32_t rank, uint32_t world_size, uint32_t log_block);
     void set_sharding(uint32_t rank, uint32_t world_size, AllGather gather);
     plk_ctx* ctx() const { return ctx_; }
     uint64_t supported_degree() const { return len_ ? len_ - 1 : 0; }

@@ -51,6 +51,14 @@ void KZGProverKey::generate_shard(const Fr& tau, const Fr& gscal, uint64_t first
     check(ctx_, plk_srs_generate_shard(ctx_, tau.v, gscal.v, first, count, len));
     len_ = len;
 }
+void KZGProverKey::generate_cyclic(const Fr& tau, const Fr& gscal, uint32_t r, uint32_t w, uint32_t log_block, uint64_t len) {
+    check(ctx_, plk_srs_generate_cyclic(ctx_, tau.v, gscal.v, r, w, log_block, len));
+    len_ = len;
+}
+void KZGProverKey::load_cyclic(const uint64_t* g_xy, uint64_t len, const uint64_t* gamma_g_xy, uint32_t r, uint32_t w, uint32_t log_block) {
+    check(ctx_, plk_srs_load_cyclic(ctx_, g_xy, len, gamma_g_xy, r, w, log_block));
+    len_ = len;
+}
 void KZGProverKey::set_sharding(uint32_t r, uint32_t w, AllGather g) { rank = r; world_size = w; gather = std::move(g); }
 
 DeviceInputs::DeviceInputs(const KZGProverKey& pk, const DensePolynomial& a, const DensePolynomial& b, const DensePolynomial& c, const DensePolynomial& q_add,

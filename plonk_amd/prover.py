@@ -18,7 +18,7 @@ from . import hip, synth
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libplonk_host.so")
-HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate",
+HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate", "plonk_pk_generate_cyclic",
                 "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
                 "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip"]
 GATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64))
@@ -110,6 +110,11 @@ class ProverKey:
     def generate_srs(self, tau, gscal, length, shard_first=0, shard_len=None):
         sl = length if shard_len is None else shard_len
         self._ck(self.lib.plonk_pk_generate(self.h, _ptr(_u64(tau, (4,))), _ptr(_u64(gscal, (4,))), C.c_uint64(shard_first), C.c_uint64(sl), C.c_uint64(length)))
+
+    def generate_srs_cyclic(self, tau, gscal, length, rank, world, log_block=12):
+        """This rank's share of a block-cyclic SRS: block b of 2^log_block powers belongs to rank b mod world."""
+        self._ck(self.lib.plonk_pk_generate_cyclic(self.h, _ptr(_u64(tau, (4,))), _ptr(_u64(gscal, (4,))), C.c_uint32(rank), C.c_uint32(world),
+                                                   C.c_uint32(log_block), C.c_uint64(length)))
 
     def set_opening_challenge(self, chal):
         self._ck(self.lib.plonk_pk_set_opening_challenge(self.h, _ptr(_u64(chal, (4,)))))

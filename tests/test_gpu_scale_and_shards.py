@@ -275,6 +275,58 @@ def test_two_logical_shards_on_one_device(orc):
         c.close()
 
 
+@pytest.mark.parametrize("world,log_block", [(2, 6), (4, 4), (8, 3), (3, 5), (8, 12)])
+def test_block_cyclic_shards_on_one_device(orc, world, log_block):
+    """Block-cyclic point ranges: `world` contexts hold every world-th block; their partial sums add up to the full MSM for any
+    range, and loading the powers from the host gives the same shard as generating them."""
+    from plonk_amd.hip import Context
+    n = 5000
+    tau, gs = synth.seeded_scalars(2, 31)
+    full = Context(0); full.srs_generate(tau, gs, n)
+    g_all = full.srs_read(0, 0, n); gg = full.srs_read(1, 0, 3)
+    shards = []
+    for r in range(world):
+        c = Context(0)
+        if r % 2 == 0:
+            c.srs_generate_cyclic(tau, gs, n, r, world, log_block)
+        else:
+            c.srs_load_cyclic(g_all, gg if r == 0 else None, r, world, log_block)
+        shards.append(c)
+    B = 1 << log_block
+    for r, c in enumerate(shards):                    # the first block of every rank that has one
+        if r * B < n:
+            cnt = min(B, n - r * B, 16)
+            assert np.array_equal(c.srs_read(0, r * B, cnt), g_all[r * B: r * B + cnt])
+    sc = synth.seeded_scalars(n, 32)
+    for (k, off) in ((n, 0), (3000, 1000), (100, 10), (1, 4999), (0, 7), (B + 3, B - 1)):
+        if off + k > n:
+            continue
+        want = full.msm(sc[:k], base_offset=off)
+        parts = []
+        for c in shards:
+            d = c.upload(sc[:k])
+            parts.append(c.msm_partial_dev(d, k, off))
+            c.free(d)
+        got = full.sum_partials(np.stack(parts))
+        assert got[1] == want[1] and np.array_equal(got[0], want[0]), (k, off)
+    # hiding commitment and opening: the gamma terms live on rank 0 only
+    coeffs = sc[:777]; blind = synth.seeded_scalars(3, 33); zeta, chal = synth.seeded_scalars(2, 34)
+    want_c = full.kzg_commit(coeffs, blind)
+    want_o = full.kzg_open(coeffs, blind, zeta, chal)
+    parts_c, parts_o = [], []
+    for c in shards:
+        d = c.upload(coeffs)
+        parts_c.append(c.end_partial(c.commit_begin(d, len(coeffs), blind))[0])
+        po, rv, ev = c.end_partial(c.open_begin(d, len(coeffs), blind, zeta, chal))
+        parts_o.append(po)
+        assert np.array_equal(rv, want_o[2]) and np.array_equal(ev, want_o[3])
+        c.free(d)
+    assert np.array_equal(full.sum_partials(np.stack(parts_c))[0], want_c[0])
+    assert np.array_equal(full.sum_partials(np.stack(parts_o))[0], want_o[0])
+    for c in [full] + shards:
+        c.close()
+
+
 WORKER = r'''
 import os, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
@@ -288,7 +340,10 @@ total = 4 * tables["n"] + 1
 per = (total + world - 1) // world
 pk = ProverKey(0)
 tau, gs = synth.seeded_scalars(2, 7)
-pk.generate_srs(tau, gs, total, shard_first=rank * per, shard_len=min(per, total - rank * per))
+if sys.argv[3] == "cyclic":
+    pk.generate_srs_cyclic(tau, gs, total, rank, world, log_block=5)
+else:
+    pk.generate_srs(tau, gs, total, shard_first=rank * per, shard_len=min(per, total - rank * per))
 def gather(mine):
     recv = [torch.zeros(mine.shape, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(recv, torch.from_numpy(mine.view(np.int64)))
@@ -303,15 +358,16 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_sharded_proof_two_processes(orc, tmp_path):
-    """Two ranks (gloo, both on this box's one GPU): each holds half of the SRS, partial sums are all-gathered, and both
-    ranks finish with the proof the unsharded prover and the CPU oracle produce."""
+@pytest.mark.parametrize("layout", ["contiguous", "cyclic"])
+def test_sharded_proof_two_processes(orc, tmp_path, layout):
+    """Two ranks (gloo, both on this box's one GPU): each holds half of the SRS (one contiguous range, or every second block),
+    partial sums are all-gathered, and both ranks finish with the proof the unsharded prover and the CPU oracle produce."""
     from plonk_amd.prover import ProverKey
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path), layout], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=280)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
