@@ -477,7 +477,11 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         s.entries_cap = cap;
     }
     PLK_TRY(tails_reserve(ctx, s, acc_lanes(max_entries, acc_run(max_entries))));
-    uint32_t nblocks = (segs.total + 8191) / 8192;
+    // 8192 scalars per workgroup for long MSMs (fewer, longer runs per bucket and chunk: measured best at 2^20 scalars); shorter ones
+    // (the per-rank share of a sharded proof) are cut finer, down to 1024, so that they still occupy a good part of the chip
+    uint32_t per_block = 8192;
+    while (per_block > 1024 && (segs.total + per_block - 1) / per_block < 128) per_block >>= 1;
+    uint32_t nblocks = (segs.total + per_block - 1) / per_block;
     if (nblocks < 1) nblocks = 1;
     if (nblocks > (uint32_t)MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
     const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
