@@ -236,12 +236,30 @@ __device__ __forceinline__ xyzz ld_tail(const uint32_t* tails, uint32_t tail_str
     }
     return r;
 }
+// The reductions of several MSMs that finish at about the same time run as one launch each (blockIdx.y = member): a reduction
+// costs about the same whatever the MSM's length, so for short MSMs (the per-rank shares of a sharded proof) one launch per MSM
+// would make the reduction stream the longest chain of a round.
+struct ReduceBatch {
+    int32_t n;
+    const uint32_t* bucket_start[MSM_SLOTS];
+    const uint32_t* tails[MSM_SLOTS];
+    const uint32_t* flushed[MSM_SLOTS];
+    uint32_t tail_stride[MSM_SLOTS];
+    uint32_t lanes_launched[MSM_SLOTS];
+    uint32_t* bucket_sums[MSM_SLOTS];
+    uint32_t* marg_part[MSM_SLOTS];
+    uint32_t* marg_dev[MSM_SLOTS];
+};
 // bucket_sums[b] = flushed[b] (if the bucket ended inside a run) + the tails of all lanes whose run ended inside bucket b.
 // FOLD_LANES lanes per bucket share the tails, a shuffle tree joins them.
 template <int FOLD_LANES>
-__global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tails, uint32_t tail_stride,
-                                                  const uint32_t* __restrict__ flushed, uint32_t lanes_launched, uint32_t* __restrict__ bucket_sums) {
+__global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(ReduceBatch rb) {
     PLK_SIDE_PRIO();
+    const uint32_t* __restrict__ bucket_start = rb.bucket_start[blockIdx.y];
+    const uint32_t* __restrict__ tails = rb.tails[blockIdx.y];
+    const uint32_t* __restrict__ flushed = rb.flushed[blockIdx.y];
+    const uint32_t tail_stride = rb.tail_stride[blockIdx.y], lanes_launched = rb.lanes_launched[blockIdx.y];
+    uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t b = t / FOLD_LANES, j = t % FOLD_LANES;
     const uint32_t first = bucket_start[b], last = bucket_start[b + 1], n_entries = bucket_start[MSM_BUCKETS];
@@ -267,8 +285,10 @@ __global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(const uint32
 // lanes all carry the same amount of work, finishes when its slowest SIMD does, and these kernels issue ahead of it.
 constexpr int MARG_SPLIT = 16;
 __device__ __forceinline__ void marginal_of(uint32_t o, uint32_t* d, uint32_t* v) { *d = o < 48 ? o >> 4 : 3; *v = o < 48 ? (o & 15) : o - 48; }
-__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(const uint32_t* __restrict__ bucket_sums, uint32_t* __restrict__ part) {
+__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(ReduceBatch rb) {
     PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
+    const uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
+    uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
     const uint32_t o = blockIdx.x / MARG_SPLIT, sp = blockIdx.x % MARG_SPLIT;
     uint32_t d, v;
     marginal_of(o, &d, &v);
@@ -282,8 +302,10 @@ __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(con
     for (int s = 32; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
     if (threadIdx.x == 0) st_xyzz(part + (size_t)blockIdx.x * XYZZ_WORDS, acc);
 }
-__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(const uint32_t* __restrict__ part, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(ReduceBatch rb) {
     PLK_SIDE_PRIO();
+    const uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
+    uint32_t* __restrict__ out = rb.marg_dev[blockIdx.y];
     const uint32_t o = blockIdx.x, lane = threadIdx.x;
     xyzz acc = lane < MARG_SPLIT ? ld_xyzz(part + ((size_t)o * MARG_SPLIT + lane) * XYZZ_WORDS) : xyzz_inf();
     for (int s = MARG_SPLIT / 2; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
@@ -513,27 +535,34 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
 // whose accumulation finished long ago.  Reductions are therefore not enqueued with their MSM but when the first result of a
 // batch is asked for, in the order in which the accumulations are expected to finish (two streams, taken alternately, each
 // kernel's time proportional to its entries).
-static int32_t enqueue_reduction(plk_ctx* ctx, MsmSlot& s) {
-    const uint32_t acc_blocks = s.acc_blocks;
+static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group) {
     hipStream_t st = ctx->st_red;
-    PLK_HIP(hipStreamWaitEvent(st, s.accumulated, 0));
-    prof_begin(ctx, st, "msm_reduce");
-    {
-        // runs that end inside an average bucket; two lanes per bucket keep the fold cheap, more lanes keep its serial chain short
-        const uint64_t tails_per_bucket = (uint64_t)acc_blocks * ACC_THREADS / MSM_BUCKETS;
-        if (tails_per_bucket <= 12)
-            hipLaunchKernelGGL(k_msm_fold<2>, dim3(MSM_BUCKETS * 2 / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
-        else if (tails_per_bucket <= 48)
-            hipLaunchKernelGGL(k_msm_fold<4>, dim3(MSM_BUCKETS * 4 / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
-        else
-            hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256), dim3(256), 0, st, s.bucket_start, s.tails, (uint32_t)s.tail_cap, s.flushed, acc_blocks * ACC_THREADS, s.bucket_sums);
+    ReduceBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    rb.n = (int32_t)group.size();
+    uint64_t tails_per_bucket = 0;
+    for (int i = 0; i < rb.n; ++i) {
+        MsmSlot& s = ctx->slot[group[i]];
+        PLK_HIP(hipStreamWaitEvent(st, s.accumulated, 0));
+        rb.bucket_start[i] = s.bucket_start; rb.tails[i] = s.tails; rb.flushed[i] = s.flushed;
+        rb.tail_stride[i] = (uint32_t)s.tail_cap; rb.lanes_launched[i] = s.acc_blocks * ACC_THREADS;
+        rb.bucket_sums[i] = s.bucket_sums; rb.marg_part[i] = s.marg_part; rb.marg_dev[i] = s.marg_dev;
+        tails_per_bucket = std::max<uint64_t>(tails_per_bucket, (uint64_t)s.acc_blocks * ACC_THREADS / MSM_BUCKETS);
     }
-    hipLaunchKernelGGL(k_msm_marginals_part, dim3(MSM_MARGINALS * MARG_SPLIT), dim3(64), 0, st, s.bucket_sums, s.marg_part);
-    hipLaunchKernelGGL(k_msm_marginals_join, dim3(MSM_MARGINALS), dim3(64), 0, st, s.marg_part, s.marg_dev);
+    prof_begin(ctx, st, "msm_reduce");
+    // runs that end inside an average bucket; two lanes per bucket keep the fold cheap, more lanes keep its serial chain short
+    if (tails_per_bucket <= 12) hipLaunchKernelGGL(k_msm_fold<2>, dim3(MSM_BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
+    else if (tails_per_bucket <= 48) hipLaunchKernelGGL(k_msm_fold<4>, dim3(MSM_BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
+    else hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
+    hipLaunchKernelGGL(k_msm_marginals_part, dim3(MSM_MARGINALS * MARG_SPLIT, rb.n), dim3(64), 0, st, rb);
+    hipLaunchKernelGGL(k_msm_marginals_join, dim3(MSM_MARGINALS, rb.n), dim3(64), 0, st, rb);
     prof_end(ctx, st);
-    PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
-    PLK_HIP(hipEventRecord(s.done, st));
     PLK_HIP(hipGetLastError());
+    for (int i = 0; i < rb.n; ++i) {
+        MsmSlot& s = ctx->slot[group[i]];
+        PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
+        PLK_HIP(hipEventRecord(s.done, st));
+    }
     return PLK_OK;
 }
 int32_t msm_flush_reductions(plk_ctx* ctx) {
@@ -547,7 +576,20 @@ int32_t msm_flush_reductions(plk_ctx* ctx) {
     }
     ctx->reduce_pending.clear();
     std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
-    for (const auto& o : order) PLK_TRY(enqueue_reduction(ctx, ctx->slot[o.second]));
+    // neighbours in that order share a launch as long as their accumulations together take well under a millisecond
+    constexpr uint64_t GROUP_ENTRIES = 12ull << 20;
+    std::vector<int> group;
+    uint64_t group_entries = 0;
+    for (const auto& o : order) {
+        const uint64_t e = ctx->slot[o.second].max_entries;
+        if (!group.empty() && group_entries + e > GROUP_ENTRIES) {
+            PLK_TRY(enqueue_reduction(ctx, group));
+            group.clear(); group_entries = 0;
+        }
+        group.push_back(o.second);
+        group_entries += e;
+    }
+    if (!group.empty()) PLK_TRY(enqueue_reduction(ctx, group));
     return PLK_OK;
 }
 

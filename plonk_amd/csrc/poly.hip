@@ -161,11 +161,21 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __r
 }
 // q_out[i - 1] = scale * h_i for i >= 1
 __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry,
-                                                           uint32_t* __restrict__ q_out, W8 scale, uint32_t first_block) {
+                                                           uint32_t* __restrict__ q_out, W8 scale, uint32_t first_block, uint32_t cyc_world, uint32_t cyc_rank,
+                                                           uint32_t cyc_log_block) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     __shared__ uint32_t heads[DIV_THREADS * 9];
     const uint32_t t = threadIdx.x, blk = first_block + blockIdx.x;
+    if (cyc_world > 1) {
+        // block-cyclic shard: q_out[k] is only used for the SRS points k this rank holds (block k >> log_block congruent to rank);
+        // a workgroup whose coefficients (k = i - 1) touch none of them has nothing to write
+        const uint64_t k_lo = blk == 0 ? 0 : (uint64_t)blk * DIV_BLOCK - 1, k_hi = (uint64_t)blk * DIV_BLOCK + DIV_BLOCK - 2;
+        const uint64_t b_lo = k_lo >> cyc_log_block, b_hi = k_hi >> cyc_log_block;
+        bool need = b_hi - b_lo + 1 >= cyc_world;
+        for (uint64_t b = b_lo; !need && b <= b_hi; ++b) need = b % cyc_world == cyc_rank;
+        if (!need) return;
+    }
     const fe z = to_rp(fe_of(zeta));
     const fe zl = div_pow2(z, 5);
     const uint64_t lo = (uint64_t)blk * DIV_BLOCK + (uint64_t)t * DIV_L;
@@ -204,6 +214,7 @@ uint64_t division_work_words(uint64_t len) {
 }
 int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
                          uint32_t* q_out, uint32_t* h0_out, uint32_t* work, uint64_t q_first, uint64_t q_count) {
+    const uint32_t cw = ctx->cyc_world, cr = ctx->cyc_rank, cl = ctx->cyc_log_block;
     if (len == 0) {
         if (h0_out) PLK_HIP(hipMemsetAsync(h0_out, 0, 32, st));
         return PLK_OK;
@@ -220,7 +231,8 @@ int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, u
         const uint64_t hi = std::min<uint64_t>(q_first + q_count, len - 1);
         if (q_first < hi) {
             const uint32_t b0 = (uint32_t)((q_first + 1) / DIV_BLOCK), b1 = (uint32_t)(hi / DIV_BLOCK);
-            hipLaunchKernelGGL(k_div_apply, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, w8_of(scale ? scale : host::FR.one), b0);
+            hipLaunchKernelGGL(k_div_apply, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, w8_of(scale ? scale : host::FR.one), b0,
+                               cw, cr, cl);
         }
     }
     prof_end(ctx, st);
