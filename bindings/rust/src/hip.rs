@@ -38,6 +38,7 @@ extern "C" {
     pub fn plk_sync(ctx: *mut plk_ctx) -> i32;
     // PCS::trim output -> HBM (src/main.rs:183)
     pub fn plk_srs_load(ctx: *mut plk_ctx, g_xy: *const u64, len: u64, gamma_g_xy: *const u64) -> i32;
+    pub fn plk_srs_setup(ctx: *mut plk_ctx, beta: *const u64, g_xy: *const u64, gamma_g_xy: *const u64, len: u64) -> i32;
     pub fn plk_srs_load_shard(ctx: *mut plk_ctx, g_xy: *const u64, shard_first: u64, shard_len: u64, total_len: u64, gamma_g_xy: *const u64) -> i32;
     // domain.fft / domain.ifft (src/prover.rs:232,233,237; src/circuit.rs:404,438,454,543; src/poly_utils.rs:9,27,28)
     pub fn plk_ntt(ctx: *mut plk_ctx, data: *mut u64, log_n: u32, inverse: i32, coset_gen: *const u64) -> i32;

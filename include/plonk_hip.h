@@ -69,6 +69,13 @@ int32_t plk_srs_generate_cyclic(plk_ctx* ctx, const uint64_t tau[4], const uint6
                                 uint32_t log_block, uint64_t total_len);
 int32_t plk_srs_load_cyclic(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t total_len, const uint64_t* gamma_g_xy_host, uint32_t rank,
                             uint32_t world, uint32_t log_block);
+/* PCS::setup + PCS::trim (src/main.rs:182-183; ark-poly-commit KZG10::setup) from the three values setup draws from its rng:
+ * powers_of_g[i] = beta^i g for i < len and powers_of_gamma_g[j] = beta^j gamma_g for j < 3, computed on the device through
+ * fixed-base window tables of g and gamma_g (arkworks' g.batch_mul(powers_of_beta)).  g and gamma_g: affine x||y, any points of the
+ * curve.  The cyclic form keeps this rank's blocks as plk_srs_generate_cyclic does (world <= 1: everything). */
+int32_t plk_srs_setup(plk_ctx* ctx, const uint64_t beta[4], const uint64_t g_xy[8], const uint64_t gamma_g_xy[8], uint64_t len);
+int32_t plk_srs_setup_cyclic(plk_ctx* ctx, const uint64_t beta[4], const uint64_t g_xy[8], const uint64_t gamma_g_xy[8], uint32_t rank,
+                             uint32_t world, uint32_t log_block, uint64_t total_len);
 /* Reads points back: which = 0 powers_of_g (global index first..first+count), 1 powers_of_gamma_g. */
 int32_t plk_srs_read(plk_ctx* ctx, int32_t which, uint64_t first, uint64_t count, uint64_t* out_xy_host);
 

@@ -680,28 +680,42 @@ extern "C" int32_t plk_srs_load(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_
     return plk_srs_load_shard(ctx, g_xy_host, 0, len, len, gamma_g_xy_host);
 }
 
-// fills the tables of the shard that srs_alloc / srs_alloc_cyclic described
-static int32_t srs_generate_points(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4]) {
+// gt[w][d] = d * 2^(8w) * base for 32 windows of 8 bits: affine, x*2^256 form, on the host
+static void fixed_base_table(const uint64_t base_xy[8], std::vector<uint64_t>& gt) {
+    using namespace host;
+    gt.assign((size_t)32 * 256 * 8, 0);
+    pt base = pt_from_affine(base_xy);
+    for (int w = 0; w < 32; ++w) {
+        pt acc = pt_inf();
+        for (int d = 1; d < 256; ++d) {
+            acc = pt_add(acc, base);
+            int32_t inf;
+            pt_to_affine(acc, &gt[((size_t)w * 256 + d) * 8], &inf);
+        }
+        for (int k = 0; k < 8; ++k) base = pt_dbl(base);
+    }
+}
+static bool g1_on_curve(const uint64_t xy[8]) {
+    using namespace host;
+    const el x = el_load(xy), y = el_load(xy + 4);
+    if (geq(x.v, FQ.p) || geq(y.v, FQ.p)) return false;
+    return eq(mul(FQ, y, y), add(FQ, mul(FQ, mul(FQ, x, x), x), from_u64(FQ, 3)));
+}
+// fills the tables of the shard that srs_alloc / srs_alloc_cyclic described: powers_of_g[i] = tau^i g and
+// powers_of_gamma_g[j] = tau^j gamma_g.  g_xy == nullptr: g is the generator (1, 2); gamma_g_xy == nullptr: gamma_g = gscal * g.
+static int32_t srs_generate_points(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], const uint64_t* g_xy = nullptr,
+                                   const uint64_t* gamma_g_xy = nullptr) {
     const uint64_t shard_first = ctx->shard_first, shard_len = ctx->shard_len;
     using namespace host;
-    // fixed-base table of the generator: gt[w][d] = d * 2^(8w) * G, affine, x*2^256 form on the host
-    std::vector<uint64_t> gt((size_t)32 * 256 * 8, 0);
-    {
+    uint64_t gen[8];
+    if (g_xy) memcpy(gen, g_xy, 64);
+    else {
         const uint64_t gx[4] = {1, 0, 0, 0}, gy[4] = {2, 0, 0, 0};
-        uint64_t gen[8];
         el x = from_canonical(FQ, gx), y = from_canonical(FQ, gy);
         memcpy(gen, x.v, 32); memcpy(gen + 4, y.v, 32);
-        pt base = pt_from_affine(gen);
-        for (int w = 0; w < 32; ++w) {
-            pt acc = pt_inf();
-            for (int d = 1; d < 256; ++d) {
-                acc = pt_add(acc, base);
-                int32_t inf;
-                pt_to_affine(acc, &gt[((size_t)w * 256 + d) * 8], &inf);
-            }
-            for (int k = 0; k < 8; ++k) base = pt_dbl(base);
-        }
     }
+    std::vector<uint64_t> gt;
+    fixed_base_table(gen, gt);
     std::vector<uint64_t> tp(40 * 4);
     {
         el t = el_load(tau);
@@ -715,14 +729,20 @@ static int32_t srs_generate_points(plk_ctx* ctx, const uint64_t tau[4], const ui
     PLK_HIP(hipMemcpy(gt_dev, gt.data(), gt.size() * 8, hipMemcpyHostToDevice));
     PLK_HIP(hipMemcpy(tp_dev, tp.data(), tp.size() * 8, hipMemcpyHostToDevice));
     uint64_t sc[8];
-    memcpy(sc, FR.one, 32); memcpy(sc + 4, gscal, 32);
+    memcpy(sc, FR.one, 32); memcpy(sc + 4, gamma_g_xy ? FR.one : gscal, 32);
     PLK_HIP(hipMemcpy(sc_dev, sc, 64, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fq_to_rp, dim3(32 * 256 * 2 / 256), dim3(256), 0, ctx->stream, gt_dev, gt_rp, (uint64_t)32 * 256 * 2);
     if (shard_len)
         hipLaunchKernelGGL(k_srs_generate, dim3((unsigned)((shard_len + 255) / 256)), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev, shard_first, shard_len, ctx->tables,
                            ctx->cyc_world, ctx->cyc_rank, ctx->cyc_log_block);
-    if (ctx->has_gamma)
+    if (ctx->has_gamma) {
+        if (gamma_g_xy) {   // the gamma powers have a base of their own: swap its table in behind the launch above
+            fixed_base_table(gamma_g_xy, gt);
+            PLK_HIP(hipMemcpyAsync(gt_dev, gt.data(), gt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_fq_to_rp, dim3(32 * 256 * 2 / 256), dim3(256), 0, ctx->stream, gt_dev, gt_rp, (uint64_t)32 * 256 * 2);
+        }
         hipLaunchKernelGGL(k_srs_generate, dim3(1), dim3(256), 0, ctx->stream, gt_rp, tp_dev, sc_dev + 8, (uint64_t)0, (uint64_t)3, ctx->tables + 16 * shard_len, 1u, 0u, 0u);
+    }
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     hipFree(gt_dev); hipFree(gt_rp); hipFree(tp_dev); hipFree(sc_dev);
@@ -741,6 +761,18 @@ extern "C" int32_t plk_srs_generate_cyclic(plk_ctx* ctx, const uint64_t tau[4], 
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_TRY(srs_alloc_cyclic(ctx, rank, world, log_block, total_len));
     return srs_generate_points(ctx, tau, gscal);
+}
+extern "C" int32_t plk_srs_setup_cyclic(plk_ctx* ctx, const uint64_t beta[4], const uint64_t g_xy[8], const uint64_t gamma_g_xy[8], uint32_t rank, uint32_t world,
+                                        uint32_t log_block, uint64_t total_len) {
+    if (!ctx || !beta || !g_xy || !gamma_g_xy) return PLK_ERR_INVALID_ARG;
+    if (!g1_on_curve(g_xy) || !g1_on_curve(gamma_g_xy)) { ctx->err = "plk_srs_setup: g or gamma_g is not a point of the curve"; return PLK_ERR_INVALID_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (world <= 1) PLK_TRY(srs_alloc(ctx, 0, total_len, total_len));
+    else PLK_TRY(srs_alloc_cyclic(ctx, rank, world, log_block, total_len));
+    return srs_generate_points(ctx, beta, nullptr, g_xy, gamma_g_xy);
+}
+extern "C" int32_t plk_srs_setup(plk_ctx* ctx, const uint64_t beta[4], const uint64_t g_xy[8], const uint64_t gamma_g_xy[8], uint64_t len) {
+    return plk_srs_setup_cyclic(ctx, beta, g_xy, gamma_g_xy, 0, 1, 0, len);
 }
 extern "C" int32_t plk_srs_load_cyclic(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t total_len, const uint64_t* gamma_g_xy_host, uint32_t rank, uint32_t world,
                                        uint32_t log_block) {

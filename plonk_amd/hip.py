@@ -20,7 +20,7 @@ STATUS = {
 # every symbol include/plonk_hip.h declares
 EXPORTS = [
     "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync", "plk_copy_dev",
-    "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_generate_cyclic", "plk_srs_load_cyclic", "plk_srs_read",
+    "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_generate_cyclic", "plk_srs_load_cyclic", "plk_srs_setup", "plk_srs_setup_cyclic", "plk_srs_read",
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
@@ -146,6 +146,11 @@ class Context:
     def srs_generate_cyclic(self, tau, gscal, length, rank, world, log_block=12):
         self._ck(self.lib.plk_srs_generate_cyclic(self.h, _ptr(_fr(tau, (4,))), _ptr(_fr(gscal, (4,))), C.c_uint32(rank), C.c_uint32(world),
                                                   C.c_uint32(log_block), C.c_uint64(length)))
+
+    def srs_setup(self, beta, g_xy, gamma_g_xy, length, rank=0, world=1, log_block=12):
+        """powers_of_g[i] = beta^i g, powers_of_gamma_g[j] = beta^j gamma_g for arbitrary points g, gamma_g (PCS::setup, src/main.rs:182)"""
+        self._ck(self.lib.plk_srs_setup_cyclic(self.h, _ptr(_fr(beta, (4,))), _ptr(_fr(g_xy, (8,))), _ptr(_fr(gamma_g_xy, (8,))), C.c_uint32(rank),
+                                               C.c_uint32(world), C.c_uint32(log_block), C.c_uint64(length)))
 
     def srs_load_cyclic(self, g_xy, gamma_g_xy, rank, world, log_block=12):
         g = _fr(g_xy, (-1, 8))

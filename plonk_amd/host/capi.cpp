@@ -90,6 +90,55 @@ int32_t plonk_verify(const uint64_t* tau, const uint64_t* gscal, const uint8_t* 
         *ok = verify_plonk_proof_with_transcript(verifier_key_from_trapdoor(t, g), proof, pub, c) ? 1 : 0;
     });
 }
+// ---- the reference's rng, setup and opening challenge (src/main.rs:25,182-183; src/prover.rs:36-59)
+int32_t plonk_rng_create(const uint8_t* seed32, void** out) { return guarded([&] { *out = seed32 ? new StdRng(seed32) : new StdRng(test_rng()); }); }
+int32_t plonk_rng_destroy(void* rng) { return guarded([&] { delete static_cast<StdRng*>(rng); }); }
+uint64_t plonk_rng_next_u64(void* rng) { return static_cast<StdRng*>(rng)->next_u64(); }
+uint32_t plonk_rng_next_u32(void* rng) { return static_cast<StdRng*>(rng)->next_u32(); }
+void plonk_rng_fr(void* rng, uint64_t n, uint64_t* out) {
+    for (uint64_t i = 0; i < n; ++i) { const Fr x = fr_rand(*static_cast<StdRng*>(rng)); memcpy(out + 4 * i, x.v, 32); }
+}
+void plonk_rng_g1(void* rng, uint64_t* xy) { const G1Affine p = g1_rand(*static_cast<StdRng*>(rng)); memcpy(xy, p.xy, 64); }
+void plonk_rng_g2(void* rng, uint64_t* x8y8) { const G2Affine p = g2_rand(*static_cast<StdRng*>(rng)); memcpy(x8y8, p.x, 64); memcpy(x8y8 + 8, p.y, 64); }
+void plonk_chacha_block(const uint8_t* key32, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t* out16) { chacha_block(key32, counter, stream, rounds, out16); }
+void plonk_test_sponge_challenge(uint64_t* out4) { const Fr c = test_sponge_challenge(); memcpy(out4, c.v, 32); }
+// vk48: g (8), gamma_g (8), h (x 8, y 8), beta_h (x 8, y 8)
+static void vk_store(const KZGVerifierKey& vk, uint64_t* o) {
+    memcpy(o, vk.g.xy, 64); memcpy(o + 8, vk.gamma_g.xy, 64); memcpy(o + 16, vk.h.x, 64); memcpy(o + 24, vk.h.y, 64); memcpy(o + 32, vk.beta_h.x, 64); memcpy(o + 40, vk.beta_h.y, 64);
+}
+static KZGVerifierKey vk_load(const uint64_t* o) {
+    KZGVerifierKey vk{};
+    memcpy(vk.g.xy, o, 64); memcpy(vk.gamma_g.xy, o + 8, 64); memcpy(vk.h.x, o + 16, 64); memcpy(vk.h.y, o + 24, 64); memcpy(vk.beta_h.x, o + 32, 64); memcpy(vk.beta_h.y, o + 40, 64);
+    return vk;
+}
+int32_t plonk_pk_setup(void* pk, uint64_t max_degree, void* rng, uint32_t rank, uint32_t world, uint32_t log_block, uint64_t* vk48) {
+    return guarded([&] { vk_store(static_cast<KZGProverKey*>(pk)->setup_cyclic(max_degree, *static_cast<StdRng*>(rng), rank, world, log_block), vk48); });
+}
+// plonk_prove drawing its blinding coefficients from the generator, as the reference's `rng: &mut R` does
+int32_t plonk_prove_rng(void* pk, void* inputs, const uint64_t* public_inputs, uint64_t n_public, void* rng, uint8_t* proof_bytes, uint64_t* challenges, double* seconds) {
+    return guarded([&] {
+        std::vector<Fr> pub(n_public);
+        if (n_public) memcpy(pub.data(), public_inputs, n_public * 32);
+        Rng draw = as_rng(*static_cast<StdRng*>(rng));
+        ProveTrace tr;
+        const PlonkProof proof = create_plonk_proof_with_transcript(*static_cast<KZGProverKey*>(pk), *static_cast<DeviceInputs*>(inputs), pub, draw, &tr);
+        const std::vector<uint8_t> bytes = serialize_proof(proof);
+        memcpy(proof_bytes, bytes.data(), bytes.size());
+        if (challenges) { memcpy(challenges, tr.beta.v, 32); memcpy(challenges + 4, tr.gamma.v, 32); memcpy(challenges + 8, tr.alpha.v, 32); memcpy(challenges + 12, tr.zeta.v, 32); }
+        if (seconds) memcpy(seconds, tr.seconds, sizeof(tr.seconds));
+    });
+}
+// src/verifier.rs:57 with an explicit verifier key (vk48 as plonk_pk_setup returns it)
+int32_t plonk_verify_vk(const uint64_t* vk48, const uint8_t* proof_bytes, uint64_t proof_len, const uint64_t* public_inputs, uint64_t n_public,
+                        const uint64_t* opening_challenge, int32_t* ok) {
+    return guarded([&] {
+        Fr c;
+        memcpy(c.v, opening_challenge, 32);
+        std::vector<Fr> pub(n_public);
+        if (n_public) memcpy(pub.data(), public_inputs, n_public * 32);
+        *ok = verify_plonk_proof_with_transcript(vk_load(vk48), deserialize_proof(proof_bytes, proof_len), pub, c) ? 1 : 0;
+    });
+}
 int32_t plonk_pairing_selftest(const uint64_t* a, const uint64_t* b) {
     Fr x, y;
     memcpy(x.v, a, 32); memcpy(y.v, b, 32);

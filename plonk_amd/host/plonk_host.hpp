@@ -70,6 +70,32 @@ struct Domain {
 // stands for `rng: &mut R`: every call is one Fr::rand(rng)
 using Rng = std::function<Fr()>;
 
+// ark_std::test_rng() (src/main.rs:25, src/prover.rs:48): rand 0.8 StdRng, which is ChaCha with 12 rounds read through a
+// 64-word block buffer.  The deterministic branch of ark-std 0.5 (environment variable DETERMINISTIC_TEST_RNG=1).
+class StdRng {
+public:
+    explicit StdRng(const uint8_t seed[32]);
+    uint32_t next_u32();
+    uint64_t next_u64();
+    bool gen_bool();              // rng.gen::<bool>(): the sign bit of one u32
+private:
+    void refill(uint32_t index);
+    uint8_t key_[32];
+    uint64_t counter_ = 0;
+    uint32_t buf_[64];
+    uint32_t index_ = 64;
+};
+StdRng test_rng();
+// one ChaCha block with rand_chacha's word layout (words 12-13 block counter, 14-15 stream id)
+void chacha_block(const uint8_t key[32], uint64_t counter, uint64_t stream, int rounds, uint32_t out[16]);
+Fr fr_rand(StdRng& rng);         // Fr::rand(rng)
+Rng as_rng(StdRng& rng);         // the same generator behind the prover's `Rng`
+struct G2Affine;
+G1Affine g1_rand(StdRng& rng);   // G1Projective::rand(rng), affine
+// the 128-bit challenge PCS::open squeezes from test_sponge() (src/prover.rs:36-59,285-303): the same value for all nine openings
+Fr test_sponge_challenge();
+struct KZGVerifierKey;
+
 // Collective used when the SRS is sharded over several GPUs: gathers every rank's `count` partial points (16 limbs each:
 // X, Y, ZZ, ZZZ) into all[world_size][count][16].  The prover calls it once per round (7, 1, 1 and 9 points), not once per
 // commitment.  Single-GPU provers pass nothing.
@@ -92,6 +118,10 @@ public:
     // ranges this spreads the prover's n-coefficient polynomials over all ranks although the SRS has 4n + 1 powers
     void generate_cyclic(const Fr& tau, const Fr& gscal, uint32_t rank, uint32_t world_size, uint32_t log_block, uint64_t len);
     void load_cyclic(const uint64_t* g_xy, uint64_t len, const uint64_t* gamma_g_xy, uint32_t rank, uint32_t world_size, uint32_t log_block);
+    // PCS::setup(max_degree, None, rng) followed by PCS::trim(&pp, max_degree, 1, None) (src/main.rs:182-183): draws beta, g, gamma_g, h
+    // from rng as KZG10::setup does, computes the max_degree + 1 powers on the GPU and returns the verifier key
+    KZGVerifierKey setup(uint64_t max_degree, StdRng& rng);
+    KZGVerifierKey setup_cyclic(uint64_t max_degree, StdRng& rng, uint32_t rank, uint32_t world_size, uint32_t log_block);
     void set_sharding(uint32_t rank, uint32_t world_size, AllGather gather);
     plk_ctx* ctx() const { return ctx_; }
     uint64_t supported_degree() const { return len_ ? len_ - 1 : 0; }
@@ -154,6 +184,7 @@ struct KZGVerifierKey {
     G1Affine g, gamma_g;
     G2Affine h, beta_h;
 };
+G2Affine g2_rand(StdRng& rng);   // G2Projective::rand(rng), affine
 // verifier key of the synthetic SRS of KZGProverKey::generate (what PCS::setup derives from its rng draws, src/main.rs:182)
 KZGVerifierKey verifier_key_from_trapdoor(const Fr& tau, const Fr& gscal);
 // src/verifier.rs:57: replays the transcript, then PCS::check for the nine openings (two pairings each).  opening_challenge is the

@@ -20,7 +20,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libplonk_host.so")
 HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate", "plonk_pk_generate_cyclic",
                 "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
-                "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip"]
+                "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip",
+                "plonk_rng_create", "plonk_rng_destroy", "plonk_rng_next_u64", "plonk_rng_next_u32", "plonk_rng_fr", "plonk_rng_g1", "plonk_rng_g2",
+                "plonk_chacha_block", "plonk_test_sponge_challenge", "plonk_pk_setup", "plonk_prove_rng", "plonk_verify_vk"]
 GATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64))
 
 _host = None
@@ -38,6 +40,10 @@ def load_host_library():
         _host.plonk_host_last_error.restype = C.c_char_p
         _host.plonk_pk_ctx.restype = C.c_void_p
         _host.plonk_pk_ctx.argtypes = [C.c_void_p]
+        _host.plonk_rng_next_u64.restype = C.c_uint64
+        _host.plonk_rng_next_u64.argtypes = [C.c_void_p]
+        _host.plonk_rng_next_u32.restype = C.c_uint32
+        _host.plonk_rng_next_u32.argtypes = [C.c_void_p]
     return _host
 
 
@@ -71,6 +77,65 @@ class DeviceInputs:
             self.close()
         except Exception:
             pass
+
+
+class StdRng:
+    """ark_std::test_rng() (src/main.rs:25) when seed is None, else rand 0.8 StdRng::from_seed(seed): ChaCha12."""
+
+    def __init__(self, seed: bytes | None = None):
+        self.lib = load_host_library()
+        h = C.c_void_p()
+        buf = None if seed is None else (C.c_uint8 * 32).from_buffer_copy(seed)
+        if self.lib.plonk_rng_create(buf, C.byref(h)) != 0:
+            raise RuntimeError("plonk_rng_create failed")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.plonk_rng_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def next_u64(self) -> int:
+        return int(self.lib.plonk_rng_next_u64(self.h))
+
+    def next_u32(self) -> int:
+        return int(self.lib.plonk_rng_next_u32(self.h))
+
+    def fr(self, n: int = 1) -> np.ndarray:
+        """n draws of Fr::rand(rng), (n, 4) uint64"""
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self.lib.plonk_rng_fr(self.h, C.c_uint64(n), _ptr(out))
+        return out
+
+    def g1(self) -> np.ndarray:
+        out = np.zeros(8, dtype=np.uint64)
+        self.lib.plonk_rng_g1(self.h, _ptr(out))
+        return out
+
+    def g2(self) -> np.ndarray:
+        """x (c0, c1), y (c0, c1): 16 words"""
+        out = np.zeros(16, dtype=np.uint64)
+        self.lib.plonk_rng_g2(self.h, _ptr(out))
+        return out
+
+
+def chacha_block(key: bytes, counter: int, stream: int, rounds: int) -> np.ndarray:
+    out = np.zeros(16, dtype=np.uint32)
+    load_host_library().plonk_chacha_block((C.c_uint8 * 32).from_buffer_copy(key), C.c_uint64(counter), C.c_uint64(stream), C.c_int32(rounds), _ptr(out))
+    return out
+
+
+def test_sponge_challenge() -> np.ndarray:
+    """The 128-bit value every PCS::open of the reference squeezes from test_sponge() (src/prover.rs:36-59,285-303), as an Fr."""
+    out = np.zeros(4, dtype=np.uint64)
+    load_host_library().plonk_test_sponge_challenge(_ptr(out))
+    return out
+
+
+test_sponge_challenge.__test__ = False     # not a pytest case
 
 
 class ProverKey:
@@ -116,6 +181,13 @@ class ProverKey:
         self._ck(self.lib.plonk_pk_generate_cyclic(self.h, _ptr(_u64(tau, (4,))), _ptr(_u64(gscal, (4,))), C.c_uint32(rank), C.c_uint32(world),
                                                    C.c_uint32(log_block), C.c_uint64(length)))
 
+    def setup(self, max_degree: int, rng: StdRng, rank: int = 0, world: int = 1, log_block: int = 12) -> np.ndarray:
+        """PCS::setup + PCS::trim (src/main.rs:182-183): draws beta, g, gamma_g, h from rng, builds the max_degree + 1 powers on the GPU.
+        Returns the verifier key as 48 words: g, gamma_g, h (x, y), beta_h (x, y)."""
+        vk = np.zeros(48, dtype=np.uint64)
+        self._ck(self.lib.plonk_pk_setup(self.h, C.c_uint64(max_degree), rng.h, C.c_uint32(rank), C.c_uint32(world), C.c_uint32(log_block), _ptr(vk)))
+        return vk
+
     def set_opening_challenge(self, chal):
         self._ck(self.lib.plonk_pk_set_opening_challenge(self.h, _ptr(_u64(chal, (4,)))))
 
@@ -154,6 +226,27 @@ class ProverKey:
         self._ck(self.lib.plonk_prove(self.h, inputs.h, _ptr(pub), C.c_uint64(0 if pub is None else len(pub)), _ptr(bl), C.c_uint64(len(bl)), _ptr(proof),
                                       _ptr(ch), _ptr(sec)))
         return ProofResult(proof.tobytes(), ch, sec)
+
+
+    def prove_rng(self, inputs: DeviceInputs, rng: StdRng, public_inputs=None) -> ProofResult:
+        """prove() with the 27 blinding coefficients drawn from rng (the reference's `rng: &mut R`, src/prover.rs:132)."""
+        pub = _u64(public_inputs, (-1, 4)) if public_inputs is not None and len(public_inputs) else None
+        proof = np.zeros(1170, dtype=np.uint8); ch = np.zeros((4, 4), dtype=np.uint64); sec = np.zeros(6, dtype=np.float64)
+        self._ck(self.lib.plonk_prove_rng(self.h, inputs.h, _ptr(pub), C.c_uint64(0 if pub is None else len(pub)), rng.h, _ptr(proof), _ptr(ch), _ptr(sec)))
+        return ProofResult(proof.tobytes(), ch, sec)
+
+
+def verify_vk(vk, proof_bytes: bytes, opening_challenge, public_inputs=None) -> bool:
+    """verify() with an explicit verifier key (the 48 words ProverKey.setup returns)."""
+    lib = load_host_library()
+    buf = np.frombuffer(proof_bytes, dtype=np.uint8).copy()
+    pub = _u64(public_inputs, (-1, 4)) if public_inputs is not None and len(public_inputs) else None
+    ok = C.c_int32(0)
+    rc = lib.plonk_verify_vk(_ptr(_u64(vk, (48,))), _ptr(buf), C.c_uint64(len(buf)), _ptr(pub), C.c_uint64(0 if pub is None else len(pub)),
+                             _ptr(_u64(opening_challenge, (4,))), C.byref(ok))
+    if rc != 0:
+        raise hip.PlonkHipError(rc, (lib.plonk_host_last_error() or b"").decode())
+    return bool(ok.value)
 
 
 def verify(tau, gscal, proof_bytes: bytes, opening_challenge, public_inputs=None) -> bool:

@@ -100,3 +100,74 @@ def test_gpu_proof_passes_the_pairing_verifier(pk, orc, log_n):
     assert prover.verify(tau, gs, proof, chal) is True
     bad = bytearray(proof); bad[40] ^= 0x10
     assert prover.verify(tau, gs, bytes(bad), chal) is False
+
+
+def _setup_points(orc, s):
+    g = orc.points_from_ints(s["powers_of_g"]); gg = orc.points_from_ints(s["powers_of_gamma_g"])
+    return g, gg
+
+
+def test_setup_powers_on_the_device(pk, orc):
+    """plk_srs_setup: PCS::setup + trim (src/main.rs:182-183) from the rng draws beta, g, gamma_g, against the CPU restatement that
+    multiplies point by point.  g and gamma_g are arbitrary curve points here, not multiples of (1, 2) with a known factor."""
+    from oracle import refrng as R
+    s = R.main_draws()["srs"]
+    want_g, want_gg = _setup_points(orc, s)
+    beta = orc.fr_from_ints([s["beta"]])[0]
+    g0, gamma0 = orc.points_from_ints([s["g"]])[0], orc.points_from_ints([s["gamma_g"]])[0]
+    pk.ctx.srs_setup(beta, g0, gamma0, 33)
+    assert np.array_equal(pk.ctx.srs_read(0, 0, 33), want_g)
+    assert np.array_equal(pk.ctx.srs_read(1, 0, 3), want_gg)
+    # block-cyclic shards of the same setup: every rank reads back its own blocks
+    for rank in range(2):
+        pk.ctx.srs_setup(beta, g0, gamma0, 33, rank=rank, world=2, log_block=2)
+        for blk in range(rank, 9, 2):
+            first, cnt = 4 * blk, min(4, 33 - 4 * blk)
+            assert np.array_equal(pk.ctx.srs_read(0, first, cnt), want_g[first:first + cnt])
+    # a point off the curve is refused
+    from plonk_amd.hip import PlonkHipError
+    bad = g0.copy(); bad[0] ^= 1
+    with pytest.raises(PlonkHipError):
+        pk.ctx.srs_setup(beta, bad, gamma0, 33)
+
+
+def test_setup_from_the_generator_equals_generate(pk, orc):
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    pk.generate_srs(tau, gs, 5000)
+    want_g, want_gg = pk.ctx.srs_read(0, 0, 5000), pk.ctx.srs_read(1, 0, 3)
+    gen = orc.points_from_ints([pm.G1_GEN])[0]
+    pk.ctx.srs_setup(tau, gen, want_gg[0], 5000)
+    assert np.array_equal(pk.ctx.srs_read(0, 0, 5000), want_g)
+    assert np.array_equal(pk.ctx.srs_read(1, 0, 3), want_gg)
+
+
+def test_replay_of_the_reference_driver(pk, orc):
+    """src/main.rs:25-230 end to end with the reference's own randomness (ark_std::test_rng, deterministic branch): the placeholder
+    draws, PCS::setup on the GPU, the proof of the example circuit with its 27 blinding coefficients drawn from the same generator and
+    the opening challenge of test_sponge, then the pairing verifier with the key of that setup.  Bytes are compared with the CPU oracle
+    run on the Python restatement of the same draws."""
+    from oracle import refrng as R
+    from plonk_amd import prover
+    tables = synth.circuit_tables(*synth.example_circuit())
+    rng = prover.StdRng()
+    rng.fr(2 * 3 * tables["n"] + 3)                       # src/main.rs:136-137,174-176
+    vk = pk.setup(32, rng)                                # src/main.rs:182-183
+    chal = prover.test_sponge_challenge()
+    pk.set_opening_challenge(chal)
+    inputs = pk.prepare(tables)
+    res = pk.prove_rng(inputs, rng)                       # src/main.rs:211
+    assert prover.verify_vk(vk, res.proof_bytes, chal) is True          # src/main.rs:226
+    d = R.main_draws()
+    s = d["srs"]
+    g, gg = _setup_points(orc, s)
+    assert np.array_equal(vk[:16].reshape(2, 8), orc.points_from_ints([s["g"], s["gamma_g"]]))
+    rc, want, ch, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], tables["log_n"], orc.fr_from_ints(d["blinds"]),
+                                orc.fr_from_ints([d["challenge"]])[0])
+    inputs.close()
+    assert rc == 0 and res.proof_bytes == want and np.array_equal(res.challenges, ch)
+    # the generator has moved on by exactly the prover's 27 draws
+    after = R.test_rng()
+    for _ in range(2 * 3 * tables["n"] + 3): R.fr_rand(after)
+    R.kzg_setup(32, after)
+    for _ in range(27): R.fr_rand(after)
+    assert rng.next_u64() == after.next_u64()
