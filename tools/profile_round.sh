@@ -21,6 +21,7 @@ stats bench20 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
 stats ntt24 python3 tools/bench_msm.py --log-n 24 --reps 5 --ntt
 stats quotient22 python3 tools/bench_msm.py --log-n 22 --reps 5 --quotient
 for c in FETCH_SIZE WRITE_SIZE; do
+    pmc bench20 $c python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --ntt-log-n 0
     pmc ntt24 $c python3 tools/bench_msm.py --log-n 24 --reps 2 --ntt
     pmc quotient22 $c python3 tools/bench_msm.py --log-n 22 --reps 2 --quotient
 done
