@@ -721,11 +721,12 @@ static int32_t srs_generate_points(plk_ctx* ctx, const uint64_t tau[4], const ui
         el t = el_load(tau);
         for (int k = 0; k < 40; ++k) { memcpy(&tp[4 * k], t.v, 32); t = mul(FR, t, t); }
     }
-    uint32_t *gt_dev = nullptr, *gt_rp = nullptr, *tp_dev = nullptr, *sc_dev = nullptr;
-    PLK_HIP(hipMalloc(&gt_dev, gt.size() * 8));
-    PLK_HIP(hipMalloc(&gt_rp, gt.size() * 8));
-    PLK_HIP(hipMalloc(&tp_dev, tp.size() * 8));
-    PLK_HIP(hipMalloc(&sc_dev, 64));
+    DevBuf gt_buf, gt_rp_buf, tp_buf, sc_buf;   // released on every path out of this function
+    PLK_HIP(gt_buf.alloc(gt.size() * 8));
+    PLK_HIP(gt_rp_buf.alloc(gt.size() * 8));
+    PLK_HIP(tp_buf.alloc(tp.size() * 8));
+    PLK_HIP(sc_buf.alloc(64));
+    uint32_t *gt_dev = (uint32_t*)gt_buf.p, *gt_rp = (uint32_t*)gt_rp_buf.p, *tp_dev = (uint32_t*)tp_buf.p, *sc_dev = (uint32_t*)sc_buf.p;
     PLK_HIP(hipMemcpy(gt_dev, gt.data(), gt.size() * 8, hipMemcpyHostToDevice));
     PLK_HIP(hipMemcpy(tp_dev, tp.data(), tp.size() * 8, hipMemcpyHostToDevice));
     uint64_t sc[8];
@@ -745,7 +746,6 @@ static int32_t srs_generate_points(plk_ctx* ctx, const uint64_t tau[4], const ui
     }
     PLK_HIP(hipGetLastError());
     PLK_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(gt_dev); hipFree(gt_rp); hipFree(tp_dev); hipFree(sc_dev);
     return srs_build_tables(ctx);
 }
 extern "C" int32_t plk_srs_generate_shard(plk_ctx* ctx, const uint64_t tau[4], const uint64_t gscal[4], uint64_t shard_first, uint64_t shard_len,

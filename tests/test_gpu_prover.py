@@ -171,3 +171,27 @@ def test_replay_of_the_reference_driver(pk, orc):
     R.kzg_setup(32, after)
     for _ in range(27): R.fr_rand(after)
     assert rng.next_u64() == after.next_u64()
+
+
+def test_proof_with_public_inputs(pk, orc):
+    """absorb_public_inputs (src/prover.rs:138, src/transcript.rs:48-52): the host prover and the verifier absorb the same message as the oracle."""
+    from plonk_amd import prover
+    variables, gates = synth.synthetic_circuit(5, seed=21)
+    tables = synth.circuit_tables(variables, gates)
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
+    chal = orc.fr_from_ints([0xFEEDFACECAFEBEEF0123456789ABCDEF])[0]
+    pk.set_opening_challenge(chal)
+    blinds = synth.seeded_scalars(27, 8)
+    pub = orc.fr_from_ints([57, pm.R_MOD - 1, 0])
+    inputs = pk.prepare(tables)
+    res = pk.prove(inputs, blinds, public_inputs=pub)
+    plain = pk.prove(inputs, blinds)
+    g = pk.ctx.srs_read(0, 0, 4 * tables["n"] + 1); gg = pk.ctx.srs_read(1, 0, 3)
+    rc, want, ch, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], tables["log_n"], blinds, chal, public_inputs=pub)
+    inputs.close()
+    assert rc == 0 and res.proof_bytes == want and np.array_equal(res.challenges, ch)
+    assert plain.proof_bytes != res.proof_bytes
+    assert prover.verify(tau, gs, res.proof_bytes, chal, public_inputs=pub) is True
+    assert prover.verify(tau, gs, res.proof_bytes, chal) is False                      # verifier replays a different transcript
+    assert prover.verify(tau, gs, res.proof_bytes, chal, public_inputs=pub[:2]) is False

@@ -163,3 +163,27 @@ def test_oracle_extended_quotient_satisfies_its_identity(orc):
     rc, _ = orc.quotient_coset(cols[0], cols[1], orc.fr_from_ints(bad), cols[3], cols[4], orc.fr_from_ints(z_vals[:n]),
                                np.array(inp["sigma"], dtype=np.uint64), f(beta), f(gamma), f(alpha))
     assert rc == 1
+
+
+def test_public_inputs_enter_the_transcript(orc):
+    """absorb_public_inputs (src/transcript.rs:48-52): one "public_inputs" message holding every element, absent when there are none.
+    The C++ oracle and the Python model must agree with public inputs present, and the proof must differ from the one without."""
+    variables, gates = pm.example_circuit()
+    inp = pm.prepare_inputs(variables, gates)
+    rng = pm.SplitMix64(77)
+    tau, gs = rng.next_fr(), rng.next_fr()
+    srs_g, srs_gg = pm.make_srs(inp["n4"] + 1, tau, gs)
+    blinds = [rng.next_fr() for _ in range(27)]
+    chal = rng.next_u64() | (rng.next_u64() << 64)
+    pub = [57, pm.R_MOD - 1, 0]
+    want = pm.prove(inp, srs_g, srs_gg, blinds, chal, public_inputs=pub)
+    polys = [orc.fr_from_ints(inp[k]) for k in ["a", "b", "c", "q_add", "q_mul", "s_id", "s_sigma"]]
+    g = orc.points_from_ints(srs_g); gg = orc.points_from_ints(srs_gg)
+    args = (g, gg, polys, orc.fr_from_ints(inp["witness_flat"]), np.array(inp["sigma"], dtype=np.uint64), 2, orc.fr_from_ints(blinds), orc.fr_from_ints([chal])[0])
+    rc, proof, ch, _ = orc.prove(*args, public_inputs=orc.fr_from_ints(pub))
+    assert rc == 0 and proof == want["bytes"]
+    rc, without, _, _ = orc.prove(*args)
+    assert rc == 0 and without != proof
+    # the first round's commitments do not depend on the transcript; everything after beta does
+    assert without[9 * 32:9 * 32 + 7 * 33] == proof[9 * 32:9 * 32 + 7 * 33]
+    assert without[:32] != proof[:32]
