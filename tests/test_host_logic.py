@@ -253,3 +253,23 @@ def test_example_circuit_proved_and_verified_on_the_cpu(orc):
     bad = bytearray(proof); o = 9 * 32
     bad[o:o + 33], bad[o + 33:o + 66] = proof[o + 33:o + 66], proof[o:o + 33]
     assert prover.verify(tau, gs, bytes(bad), chal) is False
+
+
+def test_host_code_under_sanitizers(tmp_path):
+    """plonk_amd/host (setup.cpp, verifier.cpp, transcript.cpp) compiled with -fsanitize=address,undefined and driven through the rng,
+    the point sampling, the sponge, one pairing check, proof decoding (good, corrupted, truncated) and a transcript challenge."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "host_sanitize")
+    host = os.path.join(ROOT, "plonk_amd", "host")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), os.path.join(host, "setup.cpp"), os.path.join(host, "verifier.cpp"),
+                           os.path.join(host, "transcript.cpp")])
+    proof_hex = json.load(open(os.path.join(ROOT, "tests", "golden", "proofs.json")))[0]["proof_hex"]
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe, proof_hex], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.split("\n")
+    assert lines[0] == "10719222850664546238" and "pairing 1" in lines and "roundtrip 1" in lines
+    assert "rejected: invalid field element encoding" in lines and "no throw" not in lines
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
