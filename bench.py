@@ -5,7 +5,7 @@
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-With N > 1 every rank keeps a contiguous range of the SRS powers (and its window tables); each MSM is the sum of the N
+With N > 1 every rank keeps every N-th block of 4096 SRS powers (and their window tables); each MSM is the sum of the N
 partial sums, exchanged as 128-byte points over RCCL; the cheap non-MSM rounds are replicated.  Rank 0 prints one JSON line.
 """
 import argparse
@@ -312,7 +312,7 @@ def main():
             out["ntt_stress"] = ntt_stress(pk.ctx, rank, world, local_rank, args.dist_backend, args.ntt_log_n, 5, dist, _torch)
         except Exception as e:   # the proof line above stands on its own
             out["ntt_stress"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args.cpu_log_gates, log_n, args.seed)
     inputs.close()
     pk.close()
