@@ -88,8 +88,10 @@ def test_msm_edge_scalars(ctx, orc, srs):
     assert inf == 1
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 10, 11, 12, 13, 16])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 def test_ntt_matches_oracle(ctx, orc, log_n):
+    """every plan of the transform up to 2^21 points: the single-pass kernel below 2^11, then two and three passes with every
+    mix of pass radices (2^5 .. 2^8) and of butterfly-stage groupings inside a pass"""
     a = rand_fr(orc, 1 << log_n, 7 + log_n)
     assert np.array_equal(ctx.ntt(a), orc.ntt(a))
     assert np.array_equal(ctx.ntt(a, inverse=True), orc.ntt(a, inverse=True))
