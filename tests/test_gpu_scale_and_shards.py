@@ -151,6 +151,37 @@ def test_stress_msm_2p24_through_the_trapdoor(orc):
     ctx.close()
 
 
+def test_msm_lengths_around_the_plan_boundaries(orc):
+    """Lengths at which the MSM's plan changes: the sort's workgroup size steps (1024 .. 8192 scalars per workgroup so that at least
+    128 workgroups run), the 2^20-point ranges a long MSM is pipelined in (above 1.5 * 2^20), ragged tails of one scalar, and windows
+    that start in the middle of the SRS.  Checked through the trapdoor: sum_i s_i tau^(off + i) G."""
+    from plonk_amd.hip import Context
+    tau_int, gs_int = 0x3C4D5E6F708192A3B4C5D6E7F8091A2B3C4D5E6F708192A3, 0x99AABBCCDDEEFF
+    n = (1 << 22) + 5
+    ctx = Context(0)
+    tau, gs = synth.to_mont([tau_int, gs_int])
+    ctx.srs_generate(tau, gs, n)
+    sc = _random_residues(n, 12)
+    d = ctx.upload(sc)
+    cases = [(131071, 0), (131072, 1), (131073, 4097), (262145, 3), (524287, 0), (1048575, 9), (1048577, 0), (1572864, 0), (1572865, 2), (2097153, 0),
+             (3145731, 11), (4194309, 0), (5, 4194304)]
+    for k, off in cases:
+        out, inf = ctx.msm_dev(d, k, base_offset=off)
+        want = synth.from_mont(orc.poly_eval(sc[:k], tau))[0] * pow(tau_int, off, pm.R_MOD) % pm.R_MOD
+        assert orc.point_to_ints(out, inf) == pm.g1_mul(want, pm.G1_GEN), (k, off)
+    # the same through tickets, several in flight at once, with blinding terms over the gamma powers
+    blind = synth.seeded_scalars(3, 5)
+    bsum = sum(b * pow(tau_int, j, pm.R_MOD) for j, b in enumerate(synth.from_mont(blind))) * gs_int % pm.R_MOD
+    lens = [1572865, 131073, 7, 1048577]
+    tickets = [ctx.commit_begin(d, k, blind) for k in lens]
+    for k, t in zip(lens, tickets):
+        out, inf = ctx.commit_end(t)
+        want = (synth.from_mont(orc.poly_eval(sc[:k], tau))[0] + bsum) % pm.R_MOD
+        assert orc.point_to_ints(out, inf) == pm.g1_mul(want, pm.G1_GEN), k
+    ctx.free(d)
+    ctx.close()
+
+
 def test_structured_scalars_through_the_trapdoor(orc):
     """Scalars a real proof can produce and a uniform sample never does: all equal (every entry of a window lands in one bucket),
     all zero, +-1, small values, a single non-zero coefficient, the largest digits."""
