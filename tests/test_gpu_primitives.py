@@ -211,3 +211,31 @@ def test_kzg_commit_open(ctx, orc, srs, length):
     assert np.array_equal(rv, orv)
     want_ev = orc.poly_eval(coeffs, zeta) if length else np.zeros(4, dtype=np.uint64)
     assert np.array_equal(ev, want_ev)
+
+
+def test_kzg_open_lengths_around_the_division_blocks(orc):
+    """The division by (X - zeta) works in blocks of 8192 coefficients with a carry across blocks: lengths on both sides of one, two
+    and several block boundaries, against the oracle's long division and MSM."""
+    from plonk_amd.hip import Context
+    c = Context(0)
+    n = 1 << 16
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    c.srs_generate(tau, gs, n + 1)
+    g = c.srs_read(0, 0, n + 1); gg = c.srs_read(1, 0, 3)
+    for length in (8191, 8192, 8193, 16384, 16385, 24577, 40000, 65536, 65537):
+        coeffs = rand_fr(orc, length, 90 + length)
+        blind = rand_fr(orc, 3, 91 + length)
+        zeta, chal = rand_fr(orc, 2, 92 + length)
+        chal = orc.fr_from_ints([orc.fr_to_ints(chal)[0] & ((1 << 128) - 1)])[0]
+        w, winf, rv, ev = c.kzg_open(coeffs, blind, zeta, chal)
+        ow, oinf, orv = orc.kzg_open(g, gg, coeffs, blind, zeta, chal)
+        assert winf == oinf and np.array_equal(w, ow), length
+        assert np.array_equal(rv, orv) and np.array_equal(ev, orc.poly_eval(coeffs, zeta)), length
+    # zeta = 0 and zeta = 1: the quotient is a shift / a running sum of the coefficients
+    coeffs = rand_fr(orc, 20000, 5); blind = rand_fr(orc, 3, 6)
+    for z in (0, 1, pm.R_MOD - 1):
+        zeta = orc.fr_from_ints([z])[0]; chal = orc.fr_from_ints([0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF])[0]
+        w, winf, rv, ev = c.kzg_open(coeffs, blind, zeta, chal)
+        ow, oinf, orv = orc.kzg_open(g, gg, coeffs, blind, zeta, chal)
+        assert winf == oinf and np.array_equal(w, ow) and np.array_equal(rv, orv) and np.array_equal(ev, orc.poly_eval(coeffs, zeta)), z
+    c.close()
