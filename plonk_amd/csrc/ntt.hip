@@ -485,6 +485,7 @@ static int32_t pass_twiddles(plk_ctx* ctx, hipStream_t st, const uint32_t* W, ui
 
 int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bool inverse, const uint64_t* coset_gen) {
     if (log_n > 27) { ctx->err = "NTT size above 2^27"; return PLK_ERR_INVALID_ARG; }
+    if (coset_gen && inverse && host::is_zero(host::el_load(coset_gen))) { ctx->err = "coset generator is zero"; return PLK_ERR_INVERSE_OF_ZERO; }
     const uint64_t n = 1ull << log_n;
     if (log_n == 0) return PLK_OK;
     const uint32_t* W;

@@ -239,3 +239,84 @@ def test_kzg_open_lengths_around_the_division_blocks(orc):
         ow, oinf, orv = orc.kzg_open(g, gg, coeffs, blind, zeta, chal)
         assert winf == oinf and np.array_equal(w, ow) and np.array_equal(rv, orv) and np.array_equal(ev, orc.poly_eval(coeffs, zeta)), z
     c.close()
+
+
+def test_failure_behaviour_follows_the_reference(orc):
+    """Where the reference panics the C ABI returns a status (and the context stays usable):
+    TooManyCoefficients (PCS::commit on a polynomial longer than the key, src/prover.rs:150), index out of bounds for a sigma entry
+    >= 3n (src/circuit.rs:508-510), .inverse().unwrap() on a zero denominator (src/circuit.rs:523), the sigma-length assertion of
+    interpolate_permutation_polynomials (src/poly_utils.rs:22); plus misuse of tickets, which the reference has no counterpart for."""
+    from plonk_amd.hip import Context, PlonkHipError
+    c = Context(0)
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    # no SRS yet
+    with pytest.raises(PlonkHipError) as e:
+        c.msm(rand_fr(orc, 4, 1))
+    assert e.value.status == "PLK_ERR_INVALID_ARG"
+    c.srs_generate(tau, gs, 65)
+    blind = rand_fr(orc, 3, 2)
+    with pytest.raises(PlonkHipError) as e:
+        c.kzg_commit(rand_fr(orc, 66, 3), blind)
+    assert e.value.status == "PLK_ERR_SRS_TOO_SHORT"
+    with pytest.raises(PlonkHipError) as e:
+        c.msm(rand_fr(orc, 10, 4), base_offset=60)
+    assert e.value.status == "PLK_ERR_SRS_TOO_SHORT"
+    # the context still works after a refused call
+    coeffs = rand_fr(orc, 65, 5)
+    g = c.srs_read(0, 0, 65); gg = c.srs_read(1, 0, 3)
+    got, inf = c.kzg_commit(coeffs, blind)
+    want, winf = orc.kzg_commit(g, gg, coeffs, blind)
+    assert inf == winf and np.array_equal(got, want)
+
+    # grand product: sigma entry out of range, then a zero factor in the denominator
+    v, gates = pm.synthetic_circuit(3, seed=5)
+    inp = pm.prepare_inputs(v, gates)
+    w = orc.fr_from_ints(inp["witness_flat"]); sigma = np.array(inp["sigma"], dtype=np.uint64)
+    beta, gamma = orc.fr_from_ints([11, 13])
+    bad = sigma.copy(); bad[7] = 3 * inp["n"]
+    with pytest.raises(PlonkHipError) as e:
+        c.grand_product(w, bad, beta, gamma)
+    assert e.value.status == "PLK_ERR_INDEX_OUT_OF_RANGE"
+    # gamma := -(w_j + beta j) makes the factor of position j vanish: the reference's inverse().unwrap() panics
+    j = int(sigma[4])
+    zero_gamma = orc.fr_from_ints([(-(inp["witness_flat"][j] + 11 * j)) % pm.R_MOD])[0]
+    with pytest.raises(PlonkHipError) as e:
+        c.grand_product(w, sigma, beta, zero_gamma)
+    assert e.value.status == "PLK_ERR_INVERSE_OF_ZERO"
+    zc = c.grand_product(w, sigma, beta, gamma)
+    assert np.array_equal(zc[1] if isinstance(zc, tuple) else zc, orc.grand_product(w, sigma, beta, gamma)[1])
+
+    # permutation interpolation: more sigma entries than the domain holds; an entry outside the domain
+    with pytest.raises(PlonkHipError) as e:
+        c.interpolate_permutation(np.arange(33, dtype=np.uint64), 5)
+    assert e.value.status == "PLK_ERR_INVALID_ARG"
+    bad = np.arange(24, dtype=np.uint64); bad[3] = 32
+    with pytest.raises(PlonkHipError) as e:
+        c.interpolate_permutation(bad, 5)
+    assert e.value.status == "PLK_ERR_INDEX_OUT_OF_RANGE"
+
+    # tickets: ending one twice, ending one that was never handed out, more tickets than slots
+    d = c.upload(coeffs)
+    t = c.commit_begin(d, 65, blind)
+    out, inf = c.commit_end(t)
+    assert np.array_equal(out, want)
+    with pytest.raises(PlonkHipError) as e:
+        c.commit_end(t)
+    assert e.value.status == "PLK_ERR_INVALID_ARG"
+    with pytest.raises(PlonkHipError) as e:
+        c.commit_end(99)
+    assert e.value.status == "PLK_ERR_INVALID_ARG"
+    tickets = []
+    with pytest.raises(PlonkHipError) as e:
+        for _ in range(64):
+            tickets.append(c.commit_begin(d, 65, blind))
+    assert e.value.status == "PLK_ERR_INVALID_ARG" and "slots are busy" in str(e.value) and len(tickets) >= 9
+    for t in tickets:
+        out, inf = c.commit_end(t)
+        assert np.array_equal(out, want)
+    # a zero coset generator has no inverse
+    with pytest.raises(PlonkHipError) as e:
+        c.ntt(rand_fr(orc, 16, 6), inverse=True, coset=orc.fr_from_ints([0])[0])
+    assert e.value.status == "PLK_ERR_INVERSE_OF_ZERO"
+    c.free(d)
+    c.close()
