@@ -183,6 +183,10 @@ int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t
  * read-back) shares one stream; it is enqueued for the whole batch at once, ordered by expected completion, either here or at
  * the first *_end of the batch.  Calling this right after the last *_begin lets that stage start while the host does other work. */
 int32_t plk_kzg_submit(plk_ctx* ctx);
+/* Gives up every open ticket: waits for the work they enqueued, discards the results and frees their slots.  No counterpart in the
+ * reference, where a panic unwinds the whole proof; a host that turns a failed status into an error and carries on calls this so that
+ * the tickets begun before the failure do not stay open. */
+int32_t plk_kzg_cancel(plk_ctx* ctx);
 /* Like *_end but returns this shard's unnormalised partial (16 limbs) instead of the affine point. */
 int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]);
 

@@ -265,6 +265,18 @@ extern "C" int32_t plk_kzg_submit(plk_ctx* ctx) {
     PLK_HIP(hipSetDevice(ctx->device));
     return msm_flush_reductions(ctx);
 }
+extern "C" int32_t plk_kzg_cancel(plk_ctx* ctx) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    // whatever the open tickets enqueued runs to completion (their buffers stay valid), then every slot is handed back
+    PLK_HIP(hipStreamSynchronize(ctx->st_sort));
+    PLK_HIP(hipStreamSynchronize(ctx->st_acc[0]));
+    PLK_HIP(hipStreamSynchronize(ctx->st_acc[1]));
+    PLK_HIP(hipStreamSynchronize(ctx->st_red));
+    ctx->reduce_pending.clear();
+    for (auto& s : ctx->slot) s.busy = false;
+    return PLK_OK;
+}
 static int32_t ticket_slot(plk_ctx* ctx, int32_t ticket, int kind, MsmSlot** out) {
     if (!ctx || ticket < 0 || ticket >= MSM_SLOTS || !ctx->slot[ticket].busy || ctx->slot[ticket].kind != kind) {
         if (ctx) ctx->err = "bad ticket";

@@ -136,7 +136,20 @@ G1Affine finish_point(const KZGProverKey& pk, int32_t ticket) {
 
 }  // namespace
 
+static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const std::vector<Fr>& public_inputs, Rng& rng, ProveTrace* trace);
+
+// The reference panics out of a failed proof and everything it had begun is dropped.  Here a failure is an exception the caller may
+// survive: the commitments and openings already enqueued on the GPU are given up first, so that the key can prove again.
 PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInputs& in, const std::vector<Fr>& public_inputs, Rng& rng, ProveTrace* trace) {
+    try {
+        return prove_rounds(pk, in, public_inputs, rng, trace);
+    } catch (...) {
+        plk_kzg_cancel(pk.ctx());
+        throw;
+    }
+}
+
+static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const std::vector<Fr>& public_inputs, Rng& rng, ProveTrace* trace) {
     plk_ctx* ctx = pk.ctx();
     const uint64_t n = in.domain.size();
     const uint32_t log_n = in.domain.log_size;

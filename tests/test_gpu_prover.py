@@ -195,3 +195,45 @@ def test_proof_with_public_inputs(pk, orc):
     assert prover.verify(tau, gs, res.proof_bytes, chal, public_inputs=pub) is True
     assert prover.verify(tau, gs, res.proof_bytes, chal) is False                      # verifier replays a different transcript
     assert prover.verify(tau, gs, res.proof_bytes, chal, public_inputs=pub[:2]) is False
+
+
+def test_prover_failure_behaviour(pk, orc):
+    """The reference's panics as plonk::Error / PlonkHipError: a wire polynomial with fewer than n coefficients (trailing zero values are
+    trimmed by from_coefficients_vec, then a_col[i] indexes out of bounds, src/circuit.rs:446), an SRS shorter than a polynomial
+    (TooManyCoefficients, src/prover.rs:150), an rng that runs dry."""
+    from plonk_amd.hip import PlonkHipError
+    variables, gates = synth.synthetic_circuit(4, seed=31)
+    tables = synth.circuit_tables(variables, gates)
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
+    pk.set_opening_challenge(orc.fr_from_ints([77])[0])
+    good = pk.prepare(tables)
+    blinds = synth.seeded_scalars(27, 4)
+    ok = pk.prove(good, blinds).proof_bytes
+    # 26 blinding scalars: the ninth commitment cannot draw its third coefficient
+    with pytest.raises(PlonkHipError) as e:
+        pk.prove(good, blinds[:26])
+    assert "rng exhausted" in str(e.value)
+    # the key still proves afterwards, with the same bytes
+    assert pk.prove(good, blinds).proof_bytes == ok
+    # a wire column whose last value is zero loses a coefficient
+    short = [p.copy() for p in good.polys]
+    short[1] = short[1][:-1]
+    inputs = pk.upload(short, tables["witness_flat"], tables["sigma"], tables["log_n"])
+    with pytest.raises(PlonkHipError) as e:
+        pk.prove(inputs, blinds)
+    assert e.value.status == "PLK_ERR_INDEX_OUT_OF_RANGE" and "index out of bounds" in str(e.value)
+    inputs.close()
+    # a key with fewer powers than s_sigma has coefficients
+    pk.generate_srs(tau, gs, 2 * tables["n"])
+    inputs = pk.upload(good.polys, tables["witness_flat"], tables["sigma"], tables["log_n"])
+    with pytest.raises(PlonkHipError) as e:
+        pk.prove(inputs, blinds)
+    assert e.value.status == "PLK_ERR_SRS_TOO_SHORT" and "TooManyCoefficients" in str(e.value)
+    inputs.close()
+    good.close()
+    # and it recovers once the key is long enough again
+    pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
+    again = pk.prepare(tables)
+    assert pk.prove(again, blinds).proof_bytes == ok
+    again.close()
