@@ -449,6 +449,18 @@ static int32_t coset_factors(plk_ctx* ctx, hipStream_t st, uint32_t log_n, bool 
     std::vector<uint64_t> key = {log_n, inverse ? 1ull : 0ull, gen[0], gen[1], gen[2], gen[3]};
     auto it = ctx->coset_factors.find(key);
     if (it != ctx->coset_factors.end()) { *out = it->second; return PLK_OK; }
+    // The tables are keyed by the generator, which the caller chooses: a caller that keeps changing it must not fill the device.
+    // At most eight are kept; past that all of them go (after everything that may still read one has run) and are rebuilt on demand.
+    constexpr size_t MAX_GENERATOR_TABLES = 8;
+    size_t held = 0;
+    for (const auto& kv : ctx->coset_factors) held += kv.first[0] != ~0ull ? 1 : 0;
+    if (held >= MAX_GENERATOR_TABLES) {
+        PLK_HIP(hipDeviceSynchronize());
+        for (auto e = ctx->coset_factors.begin(); e != ctx->coset_factors.end();) {
+            if (e->first[0] != ~0ull) { (void)hipFree(e->second); e = ctx->coset_factors.erase(e); }
+            else ++e;
+        }
+    }
     const uint64_t n = 1ull << log_n;
     host::el g = host::el_load(gen), base = host::one(host::FR);
     if (inverse) {

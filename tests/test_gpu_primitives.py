@@ -320,3 +320,19 @@ def test_failure_behaviour_follows_the_reference(orc):
     assert e.value.status == "PLK_ERR_INVERSE_OF_ZERO"
     c.free(d)
     c.close()
+
+
+def test_many_coset_generators(ctx, orc):
+    """Large coset transforms keep a table of per-element factors per generator; a caller that uses many generators gets correct
+    results throughout and the number of tables stays bounded (twenty generators here, eight tables kept)."""
+    log_n = 12
+    a = rand_fr(orc, 1 << log_n, 123)
+    d = ctx.upload(a)
+    for k in range(20):
+        g = orc.fr_from_ints([5 + 2 * k])[0]
+        ctx.ntt_dev(d, log_n, coset=g)
+        if k % 5 == 0:
+            assert np.array_equal(ctx.download(d, (1 << log_n, 4)), orc.ntt(a, coset=g)), k
+        ctx.ntt_dev(d, log_n, inverse=True, coset=g)
+    assert np.array_equal(ctx.download(d, (1 << log_n, 4)), a)
+    ctx.free(d)
