@@ -61,7 +61,7 @@ struct MsmSlot {
     uint32_t* tails = nullptr;         // [XYZZ_WORDS][tail_cap] what each accumulation lane held at the end of its run
     uint64_t tail_cap = 0;
     uint32_t* marg_dev = nullptr;      // [MSM_MARGINALS][32]
-    uint32_t* marg_part = nullptr;     // [MSM_MARGINALS][16][XYZZ_WORDS] partial marginal sums
+    uint32_t* marg_part = nullptr;     // [16384][XYZZ_WORDS] partial marginal sums (every lane of k_msm_marginals_part stores one)
     uint32_t* marg_host = nullptr;     // pinned
     uint32_t* blind_dev = nullptr;     // 3 Fr (+ room for opening scalars)
     uint32_t* blind_host = nullptr;    // pinned staging

@@ -279,36 +279,43 @@ __global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(ReduceBatch 
 }
 
 // Output o of the 56 marginal sums: group d of the bucket index (bits [4d, 4d+4), the last group has 3 bits) equal to v.
-// Two kernels.  The first spreads every output over MARG_SPLIT single-wave workgroups (896 waves, about one per SIMD of the chip,
-// each adding two or four buckets per lane and folding the wave with shuffles); the second joins the MARG_SPLIT partial sums of
-// an output.  Short waves on every SIMD instead of long ones on a few: the accumulation kernel of the neighbouring MSM, whose
-// lanes all carry the same amount of work, finishes when its slowest SIMD does, and these kernels issue ahead of it.
-constexpr int MARG_SPLIT = 16;
+// Two kernels.  In the first every lane adds MARG_K buckets of one output one after the other and stores its sum: no lane idles in a
+// shuffle tree, so a batch of nine MSMs (2304 waves) costs the chip little more than one does.  The second joins the partial sums of an
+// output (256 of them, 512 for the outputs of the 3-bit group, which have twice the members): a few per lane, then one shuffle tree.
+constexpr int MARG_K = 8;
+constexpr int MARG_PART_A = (MSM_BUCKETS >> 4) / MARG_K, MARG_PART_B = (MSM_BUCKETS >> 3) / MARG_K;   // partial sums per output: 256, 512
+constexpr int MARG_PARTIALS = 48 * MARG_PART_A + 8 * MARG_PART_B;                                     // 16384 per MSM
 __device__ __forceinline__ void marginal_of(uint32_t o, uint32_t* d, uint32_t* v) { *d = o < 48 ? o >> 4 : 3; *v = o < 48 ? (o & 15) : o - 48; }
 __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(ReduceBatch rb) {
     PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
     const uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
     uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
-    const uint32_t o = blockIdx.x / MARG_SPLIT, sp = blockIdx.x % MARG_SPLIT;
+    const uint32_t lane_id = blockIdx.x * 64 + threadIdx.x;     // < MARG_PARTIALS
+    uint32_t o, p, stride;
+    if (lane_id < 48 * MARG_PART_A) { o = lane_id / MARG_PART_A; p = lane_id % MARG_PART_A; stride = MARG_PART_A; }
+    else { const uint32_t r = lane_id - 48 * MARG_PART_A; o = 48 + r / MARG_PART_B; p = r % MARG_PART_B; stride = MARG_PART_B; }
     uint32_t d, v;
     marginal_of(o, &d, &v);
     const uint32_t shift = 4 * d, bits = d < 3 ? 4 : 3;
-    const uint32_t members = MSM_BUCKETS >> bits;
     xyzz acc = xyzz_inf();
-    for (uint32_t m = sp * 64 + threadIdx.x; m < members; m += 64 * MARG_SPLIT) {
+#pragma unroll 1
+    for (int j = 0; j < MARG_K; ++j) {
+        const uint32_t m = p + (uint32_t)j * stride;            // neighbouring lanes read neighbouring members
         const uint32_t idx = ((m >> shift) << (shift + bits)) | (v << shift) | (m & ((1u << shift) - 1));
         acc = xyzz_add(acc, ld_xyzz(bucket_sums + (size_t)idx * XYZZ_WORDS));
     }
-    for (int s = 32; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
-    if (threadIdx.x == 0) st_xyzz(part + (size_t)blockIdx.x * XYZZ_WORDS, acc);
+    st_xyzz(part + (size_t)lane_id * XYZZ_WORDS, acc);
 }
 __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(ReduceBatch rb) {
     PLK_SIDE_PRIO();
     const uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
     uint32_t* __restrict__ out = rb.marg_dev[blockIdx.y];
     const uint32_t o = blockIdx.x, lane = threadIdx.x;
-    xyzz acc = lane < MARG_SPLIT ? ld_xyzz(part + ((size_t)o * MARG_SPLIT + lane) * XYZZ_WORDS) : xyzz_inf();
-    for (int s = MARG_SPLIT / 2; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
+    const uint32_t first = o < 48 ? o * MARG_PART_A : 48 * MARG_PART_A + (o - 48) * MARG_PART_B, count = o < 48 ? MARG_PART_A : MARG_PART_B;
+    xyzz acc = xyzz_inf();
+#pragma unroll 1
+    for (uint32_t k = lane; k < count; k += 64) acc = xyzz_add(acc, ld_xyzz(part + (size_t)(first + k) * XYZZ_WORDS));
+    for (int s = 32; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
     if (lane == 0) {
         uint32_t* dst = out + (size_t)o * 32;
         const fe to_r = fe_const(FqP::TO_R);
@@ -380,7 +387,7 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     PLK_HIP(hipMalloc(&s.bucket_sums, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
     PLK_HIP(hipMalloc(&s.flushed, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
     PLK_HIP(hipMalloc(&s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4));
-    PLK_HIP(hipMalloc(&s.marg_part, (size_t)MSM_MARGINALS * MARG_SPLIT * XYZZ_WORDS * 4));
+    PLK_HIP(hipMalloc(&s.marg_part, (size_t)MARG_PARTIALS * XYZZ_WORDS * 4));
     PLK_HIP(hipHostMalloc(&s.marg_host, (size_t)MSM_MARGINALS * 32 * 4, hipHostMallocDefault));
     PLK_HIP(hipMalloc(&s.blind_dev, 64 * 4));
     PLK_HIP(hipHostMalloc(&s.blind_host, 64 * 4, hipHostMallocDefault));
@@ -554,7 +561,7 @@ static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group) {
     if (tails_per_bucket <= 12) hipLaunchKernelGGL(k_msm_fold<2>, dim3(MSM_BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
     else if (tails_per_bucket <= 48) hipLaunchKernelGGL(k_msm_fold<4>, dim3(MSM_BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
     else hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
-    hipLaunchKernelGGL(k_msm_marginals_part, dim3(MSM_MARGINALS * MARG_SPLIT, rb.n), dim3(64), 0, st, rb);
+    hipLaunchKernelGGL(k_msm_marginals_part, dim3(MARG_PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
     hipLaunchKernelGGL(k_msm_marginals_join, dim3(MSM_MARGINALS, rb.n), dim3(64), 0, st, rb);
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
