@@ -66,6 +66,7 @@ extern "C" {
     pub fn plk_kzg_open_begin(ctx: *mut plk_ctx, coeffs_dev: *const c_void, len: u64, blind: *const u64, zeta: *const u64, challenge: *const u64, ticket: *mut i32) -> i32;
     pub fn plk_kzg_submit(ctx: *mut plk_ctx) -> i32;
     pub fn plk_kzg_cancel(ctx: *mut plk_ctx) -> i32;
+    pub fn plk_kzg_ready(ctx: *mut plk_ctx, ticket: i32, ready: *mut i32) -> i32;
     pub fn plk_kzg_open_end(ctx: *mut plk_ctx, ticket: i32, w_xy: *mut u64, w_is_inf: *mut i32, random_v: *mut u64, eval: *mut u64) -> i32;
 }
 

@@ -183,6 +183,10 @@ int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t
  * read-back) shares one stream; it is enqueued for the whole batch at once, ordered by expected completion, either here or at
  * the first *_end of the batch.  Calling this right after the last *_begin lets that stage start while the host does other work. */
 int32_t plk_kzg_submit(plk_ctx* ctx);
+/* *ready = 1 when the ticket's result has arrived and its *_end will not wait.  A host with several tickets open ends the ready ones
+ * first: each *_end finishes its MSM with about a hundred point additions on the CPU, which then run while the GPU is still busy with
+ * the others instead of after the last one. */
+int32_t plk_kzg_ready(plk_ctx* ctx, int32_t ticket, int32_t* ready);
 /* Gives up every open ticket: waits for the work they enqueued, discards the results and frees their slots.  No counterpart in the
  * reference, where a panic unwinds the whole proof; a host that turns a failed status into an error and carries on calls this so that
  * the tickets begun before the failure do not stay open. */

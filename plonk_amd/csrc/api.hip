@@ -265,6 +265,15 @@ extern "C" int32_t plk_kzg_submit(plk_ctx* ctx) {
     PLK_HIP(hipSetDevice(ctx->device));
     return msm_flush_reductions(ctx);
 }
+extern "C" int32_t plk_kzg_ready(plk_ctx* ctx, int32_t ticket, int32_t* ready) {
+    if (!ctx || !ready || ticket < 0 || ticket >= MSM_SLOTS || !ctx->slot[ticket].busy) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(msm_flush_reductions(ctx));
+    const hipError_t e = hipEventQuery(ctx->slot[ticket].done);
+    if (e != hipSuccess && e != hipErrorNotReady) { ctx->err = hipGetErrorString(e); return PLK_ERR_HIP; }
+    *ready = e == hipSuccess ? 1 : 0;
+    return PLK_OK;
+}
 extern "C" int32_t plk_kzg_cancel(plk_ctx* ctx) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));

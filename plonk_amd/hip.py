@@ -26,7 +26,7 @@ EXPORTS = [
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
     "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
-    "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
+    "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
 ]
 
@@ -240,6 +240,11 @@ class Context:
     def grand_product_values_dev(self, d_w, d_sigma, log_n, beta, gamma, d_vals, d_out):
         self._ck(self.lib.plk_grand_product_values_dev(self.h, _vp(d_w), _vp(d_sigma), C.c_uint32(log_n), _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))),
                                                        _vp(d_vals), _vp(d_out)))
+
+    def ready(self, ticket) -> bool:
+        r = C.c_int32(0)
+        self._ck(self.lib.plk_kzg_ready(self.h, C.c_int32(ticket), C.byref(r)))
+        return bool(r.value)
 
     def cancel(self):
         """gives up every open ticket (after a failed call in the middle of a batch)"""

@@ -94,17 +94,35 @@ namespace {
 
 // Ends `count` tickets and returns their points.  With a sharded SRS every ticket yields this rank's partial sum; all partial sums
 // of the call travel in one collective and are added on the host (EC addition is not an RCCL reduction).
-void finish_points(const KZGProverKey& pk, const int32_t* tickets, int count, bool is_open, G1Affine* out, Fr* random_v, Fr* eval) {
+// `order`: the sequence in which the tickets were begun (nullptr: as listed).  Every end finishes its MSM on the CPU (about a hundred
+// point additions), so the tickets whose results have arrived are ended first, while the GPU still works on the others; when none
+// is ready the one begun earliest is waited for.
+void finish_points(const KZGProverKey& pk, const int32_t* tickets, int count, bool is_open, G1Affine* out, Fr* random_v, Fr* eval, const int* order = nullptr) {
     plk_ctx* ctx = pk.ctx();
+    std::vector<int> pending(count);
+    for (int k = 0; k < count; ++k) pending[k] = order ? order[k] : k;
+    auto take_next = [&]() {
+        size_t pick = 0;
+        for (size_t k = 0; k < pending.size() && pending.size() > 1; ++k) {
+            int32_t ready = 0;
+            check(ctx, plk_kzg_ready(ctx, tickets[pending[k]], &ready));
+            if (ready) { pick = k; break; }
+        }
+        const int i = pending[pick];
+        pending.erase(pending.begin() + pick);
+        return i;
+    };
     if (pk.world_size <= 1) {
-        for (int i = 0; i < count; ++i) {
+        while (!pending.empty()) {
+            const int i = take_next();
             if (is_open) check(ctx, plk_kzg_open_end(ctx, tickets[i], out[i].xy, &out[i].infinity, random_v[i].v, eval[i].v));
             else check(ctx, plk_kzg_commit_end(ctx, tickets[i], out[i].xy, &out[i].infinity));
         }
         return;
     }
     std::vector<uint64_t> mine((size_t)16 * count), all((size_t)16 * count * pk.world_size), one((size_t)16 * pk.world_size);
-    for (int i = 0; i < count; ++i) {
+    while (!pending.empty()) {
+        const int i = take_next();
         Fr rv{}, ev{};
         check(ctx, plk_kzg_end_partial(ctx, tickets[i], &mine[(size_t)16 * i], rv.v, ev.v));
         if (is_open) { random_v[i] = rv; eval[i] = ev; }
@@ -188,7 +206,7 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
             check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
         }
         G1Affine c7[7];
-        finish_points(pk, ticket, 7, false, c7, nullptr, nullptr);
+        finish_points(pk, ticket, 7, false, c7, nullptr, nullptr, order);
         for (int i = 0; i < 7; ++i) comm[i].comm = c7[i];
     }
     transcript.absorb_commitment("q_add", proof.comm_q_add);                    // :168-194
@@ -258,7 +276,7 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
         check(ctx, plk_kzg_submit(ctx));
         G1Affine w9[9];
         Fr rv9[9];
-        finish_points(pk, ticket, 9, true, w9, rv9, eval);
+        finish_points(pk, ticket, 9, true, w9, rv9, eval, order);
         for (int i = 0; i < 9; ++i) { open[i].w = w9[i]; open[i].random_v = rv9[i]; }
     }
     transcript.absorb_evaluations(proof.eval_a, proof.eval_b, proof.eval_c, proof.eval_q_add, proof.eval_q_mul, proof.eval_s_id, proof.eval_s_sigma,
