@@ -91,8 +91,17 @@ def cpu_baseline(log_gates_sample, log_gates, seed):
     assert oks == [0] * threads
     all_cores = {"value": round(dt_all / threads * 2.0 ** (log_gates - small) * 1e3, 1), "unit": "ms per proof (throughput)", "cores": threads,
                  "sample": f"{threads} independent single-threaded provers of a 2^{small}-gate circuit side by side: {dt_all:.2f} s for {threads} proofs, scaled to 2^{log_gates} gates"}
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
-        "value": round(dt * scale * 1e3, 1), "unit": "ms", "cores": 1, "kind": "port",
+        "value": round(dt * scale * 1e3, 1), "unit": "ms", "cores": 1, "kind": "port", "cpu_model": cpu_model,
         "sample": f"oracle/oracle.cpp (restated reference CPU path: dead s_sigma_vals loop of src/prover.rs:240 and debug prints removed) proving a 2^{log_gates_sample}-gate "
                   f"circuit of the same family in {dt:.2f} s on 1 thread, scaled x{int(scale)} to 2^{log_gates} gates (MSM-dominated, linear in n)",
         "measured_s": round(dt, 3), "stage_s": [round(float(x), 3) for x in stages], "all_cores": all_cores,
