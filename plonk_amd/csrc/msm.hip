@@ -5,14 +5,15 @@
 // single set of 2^15 buckets:  sum_i s_i P_i = sum_k k * B_k,  B_k = sum of +-T[j][i] over all (i, j)
 // whose signed 16-bit digit has magnitude k.
 //
-// Pipeline of one MSM (all on one stream, several MSMs in flight on different streams):
-//   count     : per-block bucket histogram of the digits in LDS (128 KiB)        -> counts[block][bucket]
-//   totals / scan / offsets : bucket sizes, bucket starts, per-(block, bucket) write cursors
-//   scatter   : second pass over the scalars, LDS cursors hand out slots          -> entries sorted by bucket
-//   accumulate: G lanes per bucket stride over the bucket's entries with mixed XYZZ additions, then a
-//               wavefront shuffle tree combines the G partial sums                -> bucket_sums
+// Pipeline of one MSM (sort on the front stream, accumulation and reduction on streams of their own, several MSMs in flight):
+//   digits    : signed 16-bit digits of every scalar, as 16 two-byte codes                       -> digits[scalar][16]
+//   count     : per workgroup (a chunk of scalars x half of the buckets) histogram in LDS (64 KiB) -> counts[chunk][bucket]
+//   totals / scan / offsets : bucket sizes, bucket starts, per-(chunk, bucket) write cursors
+//   scatter   : second pass over the digit codes, LDS cursors hand out slots      -> entries sorted by bucket
+//   accumulate: every lane adds one run of consecutive sorted entries (mixed XYZZ additions); sums of runs that end inside a
+//               bucket are joined by the fold kernel                              -> bucket_sums
 //   marginals : sum_k k B_k is linear in the bits of k; the bucket index is cut into 4 bit-fields and the
-//               56 sums "all buckets whose field d equals v" come from one block-wide tree each
+//               56 sums "all buckets whose field d equals v" come from serial partial sums and one tree each
 //   host      : ~130 point additions and one inversion finish the job (a GPU lane needs ~6 us per point
 //               addition, a host core ~0.3 us, so the serial tail belongs on the host).
 #include "common.cuh"
@@ -54,25 +55,51 @@ __device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint3
 }
 
 constexpr int SORT_THREADS = 256;   // four waves per block: a block fits beside the accumulation kernel's waves on a busy CU
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ counts) {
+// Digits of every scalar, once per MSM: sixteen 16-bit codes per scalar, bit 15 = sign, bits 0-14 = bucket (|d| - 1); 0xffff = no entry
+// (d = 0; the code would otherwise mean d = -2^15, which the signed recoding never produces).  The counting and the scattering pass
+// read these 32 bytes per scalar instead of converting the scalar out of Montgomery form again.
+constexpr uint32_t DIGIT_NONE = 0xffffu;
+__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs segs, uint32_t* __restrict__ digits) {
+    PLK_SIDE_PRIO();
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= segs.total) return;
+    uint32_t ti;
+    const uint32_t* sp = seg_scalar(segs, idx, &ti);
+    int32_t d[MSM_WINDOWS];
+    scalar_digits(sp, d);
+    uint32_t w[MSM_WINDOWS / 2];
+#pragma unroll
+    for (int j = 0; j < MSM_WINDOWS; j += 2) {
+        const uint32_t lo = d[j] == 0 ? DIGIT_NONE : ((d[j] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1));
+        const uint32_t hi = d[j + 1] == 0 ? DIGIT_NONE : ((d[j + 1] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j + 1] < 0 ? -d[j + 1] : d[j + 1]) - 1));
+        w[j / 2] = lo | (hi << 16);
+    }
+    store8(digits + 8ull * idx, w);
+}
+// Each workgroup takes a chunk of scalars and one of 2^log_split bucket ranges: the histogram in LDS covers that range only, and the
+// pieces a workgroup later writes per bucket are 2^log_split times longer than they would be with one workgroup per chunk.
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const uint32_t* __restrict__ digits, uint32_t total, uint32_t chunk, uint32_t* __restrict__ counts,
+                                                            uint32_t log_split) {
     PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
-    extern __shared__ uint32_t hist[];   // MSM_BUCKETS counters; dynamic so that the compiler does not pad the register allocation to the LDS-limited occupancy
-    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) hist[i] = 0;
+    extern __shared__ uint32_t hist[];   // counters of this workgroup's bucket range; dynamic so that the compiler does not pad the register allocation to the LDS-limited occupancy
+    const uint32_t nb = MSM_BUCKETS >> log_split, range = blockIdx.y, range_shift = 15 - log_split;
+    for (uint32_t i = threadIdx.x; i < nb; i += SORT_THREADS) hist[i] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk;
-    const uint32_t hi = min(lo + chunk, segs.total);
+    const uint32_t hi = min(lo + chunk, total);
     for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
-        uint32_t ti;
-        const uint32_t* sp = seg_scalar(segs, idx, &ti);
-        int32_t d[MSM_WINDOWS];
-        scalar_digits(sp, d);
+        uint32_t w[8];
+        load8(digits + 8ull * idx, w);
 #pragma unroll
-        for (int j = 0; j < MSM_WINDOWS; ++j)
-            if (d[j] != 0) atomicAdd(&hist[(d[j] < 0 ? -d[j] : d[j]) - 1], 1u);
+        for (int j = 0; j < MSM_WINDOWS; ++j) {
+            const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            const uint32_t b = code & 0x7fffu;
+            if (code != DIGIT_NONE && (b >> range_shift) == range) atomicAdd(&hist[b & (nb - 1)], 1u);
+        }
     }
     __syncthreads();
-    uint32_t* row = counts + (size_t)blockIdx.x * MSM_BUCKETS;
-    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) row[i] = hist[i];
+    uint32_t* row = counts + (size_t)blockIdx.x * MSM_BUCKETS + (size_t)range * nb;
+    for (uint32_t i = threadIdx.x; i < nb; i += SORT_THREADS) row[i] = hist[i];
 }
 
 __global__ void __launch_bounds__(256) k_msm_totals(const uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ totals) {
@@ -119,26 +146,28 @@ __global__ void __launch_bounds__(256) k_msm_offsets(uint32_t* __restrict__ coun
         run += c;
     }
 }
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(MsmSegs segs, uint32_t chunk, const uint32_t* __restrict__ offsets, uint32_t table_stride,
-                                                      uint32_t* __restrict__ entries) {
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(MsmSegs segs, const uint32_t* __restrict__ digits, uint32_t chunk, const uint32_t* __restrict__ offsets,
+                                                              uint32_t table_stride, uint32_t* __restrict__ entries, uint32_t log_split) {
     PLK_SIDE_PRIO();
-    extern __shared__ uint32_t cursor[];   // MSM_BUCKETS write cursors (dynamic LDS, see k_msm_count)
-    const uint32_t* row = offsets + (size_t)blockIdx.x * MSM_BUCKETS;
-    for (uint32_t i = threadIdx.x; i < MSM_BUCKETS; i += SORT_THREADS) cursor[i] = row[i];
+    extern __shared__ uint32_t cursor[];   // write cursors of this workgroup's bucket range (dynamic LDS, see k_msm_count)
+    const uint32_t nb = MSM_BUCKETS >> log_split, range = blockIdx.y, range_shift = 15 - log_split;
+    const uint32_t* row = offsets + (size_t)blockIdx.x * MSM_BUCKETS + (size_t)range * nb;
+    for (uint32_t i = threadIdx.x; i < nb; i += SORT_THREADS) cursor[i] = row[i];
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk;
     const uint32_t hi = min(lo + chunk, segs.total);
     for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
         uint32_t ti;
-        const uint32_t* sp = seg_scalar(segs, idx, &ti);
-        int32_t d[MSM_WINDOWS];
-        scalar_digits(sp, d);
+        (void)seg_scalar(segs, idx, &ti);      // only the table index of scalar idx is needed here
+        uint32_t w[8];
+        load8(digits + 8ull * idx, w);
 #pragma unroll
         for (int j = 0; j < MSM_WINDOWS; ++j) {
-            if (d[j] == 0) continue;
-            const uint32_t neg = d[j] < 0 ? 1u : 0u;
-            const uint32_t slot = atomicAdd(&cursor[(neg ? -d[j] : d[j]) - 1], 1u);
-            entries[slot] = (neg << 31) | ((uint32_t)j * table_stride + ti);
+            const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            const uint32_t b = code & 0x7fffu;
+            if (code == DIGIT_NONE || (b >> range_shift) != range) continue;
+            const uint32_t slot = atomicAdd(&cursor[b & (nb - 1)], 1u);
+            entries[slot] = ((code & 0x8000u) << 16) | ((uint32_t)j * table_stride + ti);
         }
     }
 }
@@ -423,11 +452,11 @@ static int32_t tails_reserve(plk_ctx* ctx, MsmSlot& s, uint64_t lanes) {
 // synchronisation) happens while proofs are running.
 static int32_t slots_reserve(plk_ctx* ctx) {
     const uint64_t max_scalars = ctx->shard_len + 3;
-    const uint64_t entries = max_scalars * MSM_WINDOWS + 1024;
+    const uint64_t entries = max_scalars * MSM_WINDOWS + 1024;   // a multiple of 16: the digit codes behind the entries are stored 16 bytes at a time
     const uint64_t scal_words = (ctx->srs_total + 1) * 8, chain_words = division_work_words(ctx->srs_total);
     for (auto& s : ctx->slot) {
         PLK_TRY(slot_init(ctx, s));
-        if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 4)); s.entries_cap = entries; }
+        if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 6)); s.entries_cap = entries; }   // 4 bytes per entry + 2 per digit code
         PLK_TRY(tails_reserve(ctx, s, acc_lanes(entries, acc_run(entries))));
         if (s.scal_cap < scal_words) { if (s.scal_dev) PLK_HIP(hipFree(s.scal_dev)); s.scal_dev = nullptr; s.scal_cap = 0; PLK_HIP(hipMalloc(&s.scal_dev, scal_words * 4)); s.scal_cap = scal_words; }
         if (s.chain_cap < chain_words) { if (s.chain_dev) PLK_HIP(hipFree(s.chain_dev)); s.chain_dev = nullptr; s.chain_cap = 0; PLK_HIP(hipMalloc(&s.chain_dev, chain_words * 4)); s.chain_cap = chain_words; }
@@ -501,26 +530,33 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     if (max_entries > s.entries_cap) {   // the slot is idle here: its previous job was waited for before it was handed out again
         if (s.entries) PLK_HIP(hipFree(s.entries));
         s.entries = nullptr; s.entries_cap = 0;
-        const uint64_t cap = max_entries + max_entries / 8 + 1024;
-        PLK_HIP(hipMalloc(&s.entries, cap * 4));
+        const uint64_t cap = (max_entries + max_entries / 8 + 1024 + 15) & ~15ull;   // the digit codes behind the entries are stored 16 bytes at a time
+        PLK_HIP(hipMalloc(&s.entries, cap * 6));   // 4 bytes per entry + 2 per digit code
         s.entries_cap = cap;
     }
     PLK_TRY(tails_reserve(ctx, s, acc_lanes(max_entries, acc_run(max_entries))));
     // 8192 scalars per workgroup for long MSMs (fewer, longer runs per bucket and chunk: measured best at 2^20 scalars); shorter ones
     // (the per-rank share of a sharded proof) are cut finer, down to 1024, so that they still occupy a good part of the chip
-    uint32_t per_block = 8192;
-    while (per_block > 1024 && (segs.total + per_block - 1) / per_block < 128) per_block >>= 1;
+    // two bucket ranges per chunk of scalars: measured best at 2^20 scalars (one range: pieces of 16 bytes per bucket and workgroup, most
+    // of them written to memory as separate 32-byte sectors; four ranges: the workgroups read every digit code four times over)
+    constexpr uint32_t log_split = 1;
+    const uint32_t split = 1u << log_split;
+    uint32_t per_block = 8192 * split;
+    while (per_block > 1024 && (uint64_t)((segs.total + per_block - 1) / per_block) * split < 128) per_block >>= 1;
     uint32_t nblocks = (segs.total + per_block - 1) / per_block;
     if (nblocks < 1) nblocks = 1;
     if (nblocks > (uint32_t)MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
     const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
     hipStream_t st = ctx->st_sort;
     prof_begin(ctx, st, "msm_sort");
-    hipLaunchKernelGGL(k_msm_count, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts);
+    uint32_t* digits = s.entries + s.entries_cap;      // 16 two-byte codes per scalar, at most entries_cap of them
+    if (segs.total) hipLaunchKernelGGL(k_msm_digits, dim3((segs.total + 255) / 256), dim3(256), 0, st, segs, digits);
+    hipLaunchKernelGGL(k_msm_count, dim3(nblocks, split), dim3(SORT_THREADS), (MSM_BUCKETS >> log_split) * 4, st, digits, segs.total, chunk, s.counts, log_split);
     hipLaunchKernelGGL(k_msm_totals, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.totals);
     hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(256), 0, st, s.totals, s.bucket_start);
     hipLaunchKernelGGL(k_msm_offsets, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.bucket_start);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks), dim3(SORT_THREADS), MSM_BUCKETS * 4, st, segs, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks, split), dim3(SORT_THREADS), (MSM_BUCKETS >> log_split) * 4, st, segs, digits, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries,
+                       log_split);
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.sorted, st));
     st = ctx->st_acc[ctx->acc_turn++ & 1];
