@@ -97,7 +97,7 @@ Fr test_sponge_challenge();
 struct KZGVerifierKey;
 
 // Collective used when the SRS is sharded over several GPUs: gathers every rank's `count` partial points (16 limbs each:
-// X, Y, ZZ, ZZZ) into all[world_size][count][16].  The prover calls it once per round (7, 1, 1 and 9 points), not once per
+// X, Y, ZZ, ZZZ) into all[world_size][count][16].  The prover calls it three times per proof (7, 2 and 9 points), not once per
 // commitment.  Single-GPU provers pass nothing.
 using AllGather = std::function<void(const uint64_t* mine, uint64_t count, uint64_t* all)>;
 

@@ -239,24 +239,25 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
 
     // ---- round 3: quotient t :224-259
     uint64_t t_len = 0;
-    try {
-        if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
-            throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
-        check(ctx, plk_quotient_dev(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4],
-                                    &t_len));
-        if (t_len != 0) {
-            finish_point(pk, t_ticket);
-            check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));
-        }
-    } catch (...) {
-        finish_point(pk, z_ticket);
+    // a failure below leaves both tickets open: the caller of prove_rounds gives them up
+    if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
+        throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
+    check(ctx, plk_quotient_dev(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4],
+                                &t_len));
+    if (t_len != 0) {
         finish_point(pk, t_ticket);
-        throw;
+        check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));
     }
-    comm[7].comm = finish_point(pk, z_ticket);
+    {
+        // both commitments in one call: with a sharded SRS their partial sums travel in one collective
+        const int32_t zt[2] = {z_ticket, t_ticket};
+        G1Affine c2[2];
+        finish_points(pk, zt, 2, false, c2, nullptr, nullptr);
+        comm[7].comm = c2[0];
+        comm[8].comm = c2[1];
+    }
     transcript.absorb_commitment("z", proof.comm_z);                           // :214-216
     const Fr alpha = transcript.challenge_alpha();                              // :219 (enters only the public-input term, which is empty)
-    comm[8].comm = finish_point(pk, t_ticket);
     transcript.absorb_commitment("t", proof.comm_t);                           // :257-259
     const Fr zeta = transcript.challenge_zeta();                                // :262
     lap(2);

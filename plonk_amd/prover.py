@@ -193,7 +193,7 @@ class ProverKey:
 
     def set_sharding(self, rank, world_size, gather):
         """gather(mine: np.ndarray(count, 16) uint64) -> np.ndarray(world_size, count, 16): the partial points of all ranks.
-        Called once per prover round (count = 7, 1, 1, 9)."""
+        Called three times per proof (count = 7, 2, 9)."""
         def cb(_user, mine, count, out):
             m = np.ctypeslib.as_array(mine, shape=(count, 16)).copy()
             res = np.ascontiguousarray(gather(m), dtype=np.uint64).reshape(world_size * count * 16)
