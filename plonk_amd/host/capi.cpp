@@ -1,6 +1,7 @@
 // C entry points of libplonk_host.so for the Python harness (tests, bench.py, smoke).  They only marshal arguments into
 // the C++ surface of plonk_host.hpp; failures come back as a status code plus the reference-style message.
 #include "plonk_host.hpp"
+#include "circuit.hpp"
 #include <string.h>
 #include <string>
 
@@ -137,6 +138,37 @@ int32_t plonk_verify_vk(const uint64_t* vk48, const uint8_t* proof_bytes, uint64
         std::vector<Fr> pub(n_public);
         if (n_public) memcpy(pub.data(), public_inputs, n_public * 32);
         *ok = verify_plonk_proof_with_transcript(vk_load(vk48), deserialize_proof(proof_bytes, proof_len), pub, c) ? 1 : 0;
+    });
+}
+// ---- circuit construction (src/circuit.rs) for the tests: rebuilds a circuit through CircuitBuilder from its variable values and
+// gates (type 0 Add / 1 Mul, a, b, out per gate; a variable that is no gate's output is a new_variable) and returns the tables of
+// Circuit::from_builder, WitnessTable::flatten and compute_sigma_mapping for the domain of 2^log_n rows.
+int32_t plonk_circuit_tables(const uint64_t* var_values, uint64_t n_vars, const int64_t* gates, uint64_t n_gates, uint32_t log_n, uint64_t* a_col, uint64_t* b_col,
+                             uint64_t* c_col, uint64_t* q_add, uint64_t* q_mul, uint64_t* witness_flat, uint64_t* sigma) {
+    return guarded([&] {
+        CircuitBuilder b;
+        uint64_t next_gate = 0;
+        for (uint64_t v = 0; v < n_vars; ++v) {
+            if (next_gate < n_gates && (uint64_t)gates[4 * next_gate + 3] == v) {
+                const int64_t* g = gates + 4 * next_gate++;
+                const Variable out = b.add_gate(g[0] == 0 ? GateType::Add : GateType::Mul, Variable{(size_t)g[1]}, Variable{(size_t)g[2]});
+                if (out.index != v || memcmp(b.variables[v].v, var_values + 4 * v, 32) != 0) throw Error(PLK_ERR_INVALID_ARG, "gate output does not match the given value");
+            } else {
+                Fr x; memcpy(x.v, var_values + 4 * v, 32);
+                b.new_variable(&x);
+            }
+        }
+        if (next_gate != n_gates) throw Error(PLK_ERR_INVALID_ARG, "gates are not in the order of their outputs");
+        const Domain domain{log_n};
+        const Circuit c = Circuit::from_builder(std::move(b), domain);
+        const size_t n = domain.size();
+        if (c.witness.a_col.size() != n) throw Error(PLK_ERR_INVALID_ARG, "more gates than rows");
+        memcpy(a_col, c.witness.a_col.data(), n * 32); memcpy(b_col, c.witness.b_col.data(), n * 32); memcpy(c_col, c.witness.c_col.data(), n * 32);
+        memcpy(q_add, c.witness.q_add.data(), n * 32); memcpy(q_mul, c.witness.q_mul.data(), n * 32);
+        const std::vector<Fr> flat = c.witness.flatten();
+        memcpy(witness_flat, flat.data(), flat.size() * 32);
+        const std::vector<uint64_t> sg = c.permutation.compute_sigma_mapping(n);
+        memcpy(sigma, sg.data(), sg.size() * 8);
     });
 }
 int32_t plonk_pairing_selftest(const uint64_t* a, const uint64_t* b) {

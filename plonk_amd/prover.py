@@ -22,7 +22,7 @@ HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", 
                 "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
                 "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip",
                 "plonk_rng_create", "plonk_rng_destroy", "plonk_rng_next_u64", "plonk_rng_next_u32", "plonk_rng_fr", "plonk_rng_g1", "plonk_rng_g2",
-                "plonk_chacha_block", "plonk_test_sponge_challenge", "plonk_pk_setup", "plonk_prove_rng", "plonk_verify_vk"]
+                "plonk_chacha_block", "plonk_test_sponge_challenge", "plonk_pk_setup", "plonk_prove_rng", "plonk_verify_vk", "plonk_circuit_tables"]
 GATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64))
 
 _host = None
@@ -120,6 +120,26 @@ class StdRng:
         out = np.zeros(16, dtype=np.uint64)
         self.lib.plonk_rng_g2(self.h, _ptr(out))
         return out
+
+
+def circuit_tables(variables, gates):
+    """The reference's CircuitBuilder / Circuit::from_builder / compute_sigma_mapping (src/circuit.rs) in the host library: same
+    result as synth.circuit_tables, which builds the tables with numpy.  variables: integers; gates: (type, a, b, out)."""
+    lib = load_host_library()
+    ng = len(gates)
+    n = 1
+    while n < ng:
+        n *= 2
+    vals = synth.to_mont(variables)
+    g = np.ascontiguousarray(np.array(gates, dtype=np.int64).reshape(-1, 4))
+    cols = [np.zeros((n, 4), dtype=np.uint64) for _ in range(5)]
+    flat = np.zeros((3 * n, 4), dtype=np.uint64)
+    sigma = np.zeros(3 * n, dtype=np.uint64)
+    rc = lib.plonk_circuit_tables(_ptr(vals), C.c_uint64(len(vals)), _ptr(g), C.c_uint64(ng), C.c_uint32(n.bit_length() - 1), *[_ptr(c) for c in cols],
+                                  _ptr(flat), _ptr(sigma))
+    if rc != 0:
+        raise hip.PlonkHipError(rc, (lib.plonk_host_last_error() or b"").decode())
+    return dict(n=n, log_n=n.bit_length() - 1, a=cols[0], b=cols[1], c=cols[2], q_add_vals=cols[3], q_mul_vals=cols[4], witness_flat=flat, sigma=sigma)
 
 
 def chacha_block(key: bytes, counter: int, stream: int, rounds: int) -> np.ndarray:

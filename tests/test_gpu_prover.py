@@ -237,3 +237,26 @@ def test_prover_failure_behaviour(pk, orc):
     again = pk.prepare(tables)
     assert pk.prove(again, blinds).proof_bytes == ok
     again.close()
+
+
+def test_cxx_replay_of_the_reference_driver(pk, orc):
+    """examples/replay_main.cpp: src/main.rs in C++ on the host library (CircuitBuilder, setup from test_rng, proof, pairing
+    verification).  Its proof must be the one the Python replay above produces."""
+    import os
+    import subprocess
+    from plonk_amd import prover
+    exe = os.path.join(os.path.dirname(prover.HOST_LIB_PATH), "replay_main")
+    assert os.path.exists(exe), "build it with make -C plonk_amd/host"
+    out = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert "Proof verified: true" in lines and "Circuit gates: 4" in lines and "Domain size: 4" in lines
+    tables = synth.circuit_tables(*synth.example_circuit())
+    rng = prover.StdRng()
+    rng.fr(2 * 3 * tables["n"] + 3)
+    pk.setup(32, rng)
+    pk.set_opening_challenge(prover.test_sponge_challenge())
+    inputs = pk.prepare(tables)
+    want = pk.prove_rng(inputs, rng).proof_bytes
+    inputs.close()
+    assert lines[0] == "proof " + want.hex()

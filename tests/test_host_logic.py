@@ -273,3 +273,30 @@ def test_host_code_under_sanitizers(tmp_path):
     assert lines[0] == "10719222850664546238" and "pairing 1" in lines and "roundtrip 1" in lines
     assert "rejected: invalid field element encoding" in lines and "no throw" not in lines
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+
+
+def test_circuit_builder_of_the_host_library():
+    """CircuitBuilder / Circuit::from_builder / WitnessTable::flatten / compute_sigma_mapping (src/circuit.rs:80-112,169-276) restated in
+    C++ (plonk_amd/host/circuit.cpp) against the numpy tables of plonk_amd/synth.py and the reference's known answers for its example."""
+    from plonk_amd import prover
+    keys = ("a", "b", "c", "q_add_vals", "q_mul_vals", "witness_flat", "sigma")
+    for variables, gates in (synth.example_circuit(), synth.synthetic_circuit(1, seed=2), synth.synthetic_circuit(5, seed=3), synth.synthetic_circuit(11, seed=4)):
+        want, got = synth.circuit_tables(variables, gates), prover.circuit_tables(variables, gates)
+        assert want["n"] == got["n"]
+        for k in keys:
+            assert np.array_equal(want[k], got[k]), k
+    # five gates in a domain of eight rows: zero padding, identity sigma on the unused rows
+    variables, gates = synth.synthetic_circuit(3, seed=9)
+    variables, gates = variables[:7], gates[:5]
+    want, got = synth.circuit_tables(variables, gates), prover.circuit_tables(variables, gates)
+    for k in keys:
+        assert np.array_equal(want[k], got[k]), k
+    assert list(got["sigma"][15:]) == list(range(15, 24))
+    ex = prover.circuit_tables(*synth.example_circuit())
+    assert list(ex["sigma"]) == [10, 1, 3, 2, 4, 6, 5, 7, 9, 8, 0, 11]
+    assert synth.from_mont(ex["witness_flat"]) == [3, 4, 7, 7, 2, 14, 14, 5, 19, 19, 3, 57]
+    # a gate whose stated output value is wrong is refused (add_gate computes the value itself)
+    from plonk_amd.hip import PlonkHipError
+    bad = list(synth.example_circuit()[0]); bad[4] += 1
+    with pytest.raises(PlonkHipError):
+        prover.circuit_tables(bad, synth.example_circuit()[1])
