@@ -239,7 +239,9 @@ def main():
 
     for _ in range(args.warmup):
         res = pk.prove(inputs, blinds)
-    pk.ctx.profile_enable(True)
+    # Inside the timed region only the dominant kernel is bracketed with events (two per MSM); the per-class breakdown of all kernels
+    # comes from two more proofs after it, outside the timed region (bracketing every class costs about 0.3 ms per proof).
+    pk.ctx.profile_enable(2)
     pk.ctx.profile_reset()
     sync()
     t0 = time.perf_counter()
@@ -255,8 +257,15 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
 
-    prof = {name: pk.ctx.profile_get(name) for name in ("msm_accumulate", "msm_sort", "msm_reduce", "ntt", "pointwise", "division")}
+    prof = {"msm_accumulate": pk.ctx.profile_get("msm_accumulate")}
     acc_busy_ms = pk.ctx.profile_get_busy("msm_accumulate")
+    breakdown_steps = 2
+    pk.ctx.profile_enable(1)
+    pk.ctx.profile_reset()
+    for _ in range(breakdown_steps):
+        pk.prove(inputs, blinds)
+    sync()
+    breakdown = {name: pk.ctx.profile_get(name) for name in ("msm_accumulate", "msm_sort", "msm_reduce", "ntt", "pointwise", "division")}
     # dominant kernel: k_msm_accumulate.  One launch per MSM; per proof the launches cover 20n + 45 (point, scalar) pairs in total.
     acc_ms, acc_launches = prof["msm_accumulate"]
     pairs_per_proof = (20 * n + 45) / world
@@ -311,7 +320,7 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else "MSM sharded over %d GPUs by block-cyclic point ranges (4096 points per block), partial sums all-gathered over RCCL; other rounds replicated" % world},
         "msm_gpts_per_s": round((20 * n + 45) / (ms_per_step * 1e-3) / 1e9, 4),
         "stage_ms": {k: round(float(v) / args.steps * 1e3, 3) for k, v in zip(["round1_commit", "grand_product", "quotient", "open", "assemble", "total"], stage)},
-        "kernel_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
+        "kernel_ms_per_proof": {k: round(v[0] / breakdown_steps, 3) for k, v in breakdown.items()},
         "roofline": roofline,
         "setup_s": round(setup_s, 2),
     }

@@ -199,6 +199,7 @@ int32_t plk_field_op(plk_ctx* ctx, int32_t field, int32_t op, const uint64_t* a_
 
 /* ---- measurement: accumulated device time (HIP events on the launching stream) and launch count of the named
  * kernel class since the last reset: "msm_accumulate", "msm_sort", "msm_reduce", "ntt", "pointwise", "division". */
+/* on: 0 off, 1 every class, 2 "msm_accumulate" only (two events per MSM: cheap enough to leave on while a run is timed). */
 int32_t plk_profile_enable(plk_ctx* ctx, int32_t on);
 int32_t plk_profile_reset(plk_ctx* ctx);
 int32_t plk_profile_get(plk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);

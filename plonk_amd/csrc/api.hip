@@ -5,6 +5,7 @@
 #include "host_math.hpp"
 #include "kernels.h"
 #include <stdio.h>
+#include <string.h>
 
 namespace plk {
 
@@ -17,17 +18,25 @@ int32_t set_err(plk_ctx* ctx, int32_t code, const char* what, hipError_t e, int 
     return code;
 }
 
+static bool prof_event(plk_ctx* ctx, hipEvent_t* e) {
+    if (!ctx->prof_free.empty()) { *e = ctx->prof_free.back(); ctx->prof_free.pop_back(); return true; }
+    return hipEventCreate(e) == hipSuccess;
+}
 void prof_begin(plk_ctx* ctx, hipStream_t s, const char* name) {
-    if (!ctx->profiling) return;
+    ctx->prof_open = false;
+    if (!ctx->profiling || (ctx->profiling == 2 && strcmp(name, "msm_accumulate") != 0)) return;
     PendingEvent p;
     p.name = name;
-    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
+    if (!prof_event(ctx, &p.e0)) return;
+    if (!prof_event(ctx, &p.e1)) { ctx->prof_free.push_back(p.e0); return; }
     hipEventRecord(p.e0, s);
     ctx->pending.push_back(p);
+    ctx->prof_open = true;
 }
 void prof_end(plk_ctx* ctx, hipStream_t s) {
-    if (!ctx->profiling || ctx->pending.empty()) return;
+    if (!ctx->prof_open) return;
     hipEventRecord(ctx->pending.back().e1, s);
+    ctx->prof_open = false;
 }
 // Books the brackets whose closing event has completed; with wait = true it blocks for all of them.  Start and end are also
 // kept relative to the event recorded at the last reset, so that the time during which at least one bracket of a name was
@@ -45,8 +54,8 @@ void prof_collect(plk_ctx* ctx, bool wait) {
             e.launches += 1;
             if (ctx->prof_base && hipEventElapsedTime(&t0, ctx->prof_base, p.e0) == hipSuccess) e.spans.push_back({(double)t0, (double)t0 + ms});
         }
-        hipEventDestroy(p.e0);
-        hipEventDestroy(p.e1);
+        ctx->prof_free.push_back(p.e0);
+        ctx->prof_free.push_back(p.e1);
     }
     ctx->pending.resize(kept);
 }
@@ -155,6 +164,7 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     hipDeviceSynchronize();
     prof_collect(ctx, true);
     if (ctx->prof_base) hipEventDestroy(ctx->prof_base);
+    for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
     for (auto& s : ctx->slot) slot_destroy(s);
     ntt_release(ctx);
     hipFree(ctx->tables); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
@@ -207,7 +217,7 @@ extern "C" int32_t plk_sync(plk_ctx* ctx) {
 
 extern "C" int32_t plk_profile_enable(plk_ctx* ctx, int32_t on) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
-    ctx->profiling = on != 0;
+    ctx->profiling = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return PLK_OK;
 }
 extern "C" int32_t plk_profile_reset(plk_ctx* ctx) {

@@ -110,7 +110,9 @@ struct plk_ctx {
     uint32_t* flag_dev = nullptr;
     uint32_t* flag_host = nullptr;
     // profiling
-    bool profiling = false;
+    int profiling = 0;                 // 0 off, 1 every kernel class, 2 "msm_accumulate" only (cheap enough to stay on while a run is timed)
+    bool prof_open = false;            // the last prof_begin recorded an event and waits for its prof_end
+    std::vector<hipEvent_t> prof_free; // events handed back by finished brackets
     hipEvent_t prof_base = nullptr;    // recorded at the last profile reset
     std::map<std::string, plk::ProfEntry> prof;
     std::vector<plk::PendingEvent> pending;
