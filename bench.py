@@ -330,6 +330,11 @@ def main():
             out["ntt_stress"] = ntt_stress(pk.ctx, rank, world, local_rank, args.dist_backend, args.ntt_log_n, 5, dist, _torch)
         except Exception as e:   # the proof line above stands on its own
             out["ntt_stress"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0:
+        # the last proof of the timed region through the pairing verifier (src/verifier.rs on the CPU, ~0.3 s, outside the timed region):
+        # at N > 1 this is the proof the ranks assembled from their partial sums
+        from plonk_amd import prover as _prover
+        out["proof_verified"] = bool(_prover.verify(tau, gscal, res.proof_bytes, synth.to_mont([0x1234567890ABCDEF1122334455667788])[0]))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args.cpu_log_gates, log_n, args.seed)
     inputs.close()
