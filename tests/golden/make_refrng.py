@@ -34,6 +34,18 @@ def main():
         "blinds": [H(x) for x in d["blinds"]],
         "opening_challenge": H(d["challenge"]),
     }
+    # the proof of the example circuit that the replay of src/main.rs produces from these draws (CPU oracle)
+    import numpy as np
+    from oracle import oracle as orc
+    from oracle import pymodel as pm
+    from plonk_amd import synth
+    inp = pm.prepare_inputs(*pm.example_circuit())
+    tables = synth.circuit_tables(*synth.example_circuit())
+    polys = [synth.trim(orc.fr_from_ints(inp[k])) for k in ("a", "b", "c", "q_add", "q_mul", "s_id", "s_sigma")]
+    rc, proof, _, _ = orc.prove(orc.points_from_ints(s["powers_of_g"]), orc.points_from_ints(s["powers_of_gamma_g"]), polys, tables["witness_flat"], tables["sigma"],
+                                tables["log_n"], orc.fr_from_ints(d["blinds"]), orc.fr_from_ints([d["challenge"]])[0])
+    assert rc == 0
+    out["replay_proof_hex"] = proof.hex()
     path = os.path.join(os.path.dirname(__file__), "refrng.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -165,6 +165,10 @@ def test_replay_of_the_reference_driver(pk, orc):
                                 orc.fr_from_ints([d["challenge"]])[0])
     inputs.close()
     assert rc == 0 and res.proof_bytes == want and np.array_equal(res.challenges, ch)
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refrng.json")))
+    assert res.proof_bytes.hex() == gold["replay_proof_hex"]
     # the generator has moved on by exactly the prover's 27 draws
     after = R.test_rng()
     for _ in range(2 * 3 * tables["n"] + 3): R.fr_rand(after)

@@ -127,6 +127,7 @@ def test_replay_of_the_reference_driver_on_the_cpu(orc):
     polys = [synth.trim(orc.fr_from_ints(inp[k])) for k in ("a", "b", "c", "q_add", "q_mul", "s_id", "s_sigma")]
     rc, proof, _, _ = orc.prove(g, gg, polys, tables["witness_flat"], tables["sigma"], tables["log_n"], blinds, chal)
     assert rc == 0 and len(proof) == 1170
+    assert proof.hex() == GOLD["replay_proof_hex"]
     vk = np.concatenate([orc.points_from_ints([s["g"], s["gamma_g"]]).reshape(-1),
                          orc.fq_from_ints([s["h"][0][0], s["h"][0][1], s["h"][1][0], s["h"][1][1]]).reshape(-1),
                          orc.fq_from_ints([s["beta_h"][0][0], s["beta_h"][0][1], s["beta_h"][1][0], s["beta_h"][1][1]]).reshape(-1)])
