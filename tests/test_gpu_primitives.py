@@ -88,9 +88,9 @@ def test_msm_edge_scalars(ctx, orc, srs):
     assert inf == 1
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_ntt_matches_oracle(ctx, orc, log_n):
-    """every plan of the transform up to 2^21 points: the single-pass kernel below 2^11, then two and three passes with every
+    """every plan of the transform up to 2^22 points (the s_sigma transform of a 2^20-gate proof): the single-pass kernel below 2^11, then two and three passes with every
     mix of pass radices (2^5 .. 2^8) and of butterfly-stage groupings inside a pass"""
     a = rand_fr(orc, 1 << log_n, 7 + log_n)
     assert np.array_equal(ctx.ntt(a), orc.ntt(a))

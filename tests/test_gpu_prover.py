@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+from conftest import assert_polys_equal, independent_polys
 from oracle import pymodel as pm
 from plonk_amd import synth
 
@@ -30,8 +31,13 @@ def _prove_both(pk, orc, variables, gates, seed):
     pk.set_opening_challenge(chal)
     inputs = pk.prepare(tables)
     res = pk.prove(inputs, blinds)
-    g = pk.ctx.srs_read(0, 0, n4 + 1); gg = pk.ctx.srs_read(1, 0, 3)
-    rc, want, ch, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], log_n, blinds, chal)
+    # the checker's inputs come from the CPU alone: interpolated polynomials and SRS powers of the oracle, compared with the device's
+    polys = independent_polys(orc, tables)
+    assert_polys_equal(inputs.polys, polys)
+    one = orc.fr_from_ints([1])[0]
+    g = orc.srs_powers(tau, one, 0, n4 + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+    assert np.array_equal(pk.ctx.srs_read(0, 0, n4 + 1), g) and np.array_equal(pk.ctx.srs_read(1, 0, 3), gg)
+    rc, want, ch, _ = orc.prove(g, gg, polys, tables["witness_flat"], tables["sigma"], log_n, blinds, chal)
     assert rc == 0
     inputs.close()
     return res, want, ch

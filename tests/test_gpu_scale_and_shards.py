@@ -8,6 +8,7 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import assert_polys_equal, independent_polys
 from oracle import pymodel as pm
 from plonk_amd import synth
 
@@ -111,11 +112,16 @@ def test_full_size_proof_through_the_trapdoor(orc, log_n):
     inputs = pk.prepare(tables)
     res = pk.prove(inputs, blinds)
     _, z_coeffs = orc.grand_product(tables["witness_flat"], tables["sigma"], res.challenges[0], res.challenges[1])
-    polys = list(inputs.polys) + [z_coeffs, np.zeros((0, 4), np.uint64)]
+    # the seven input polynomials the identities are checked with are interpolated by the oracle (4n-point transforms on the CPU),
+    # and must equal what the device interpolated (src/poly_utils.rs:14-31, src/main.rs:190-191) byte for byte
+    own = independent_polys(orc, tables)
+    assert_polys_equal(inputs.polys, own)
+    polys = own + [z_coeffs, np.zeros((0, 4), np.uint64)]
     _check_proof_with_trapdoor(orc, res.proof_bytes, res.challenges[3], polys, blinds, chal_int, tau_int, gs_int)
-    if log_n == 16:   # the CPU oracle still proves 2^16 gates in seconds: compare every byte
-        g = pk.ctx.srs_read(0, 0, 4 * n + 1); gg = pk.ctx.srs_read(1, 0, 3)
-        rc, want, ch, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], log_n, blinds, synth.to_mont([chal_int])[0])
+    if log_n == 16:   # the CPU oracle still proves 2^16 gates in seconds: compare every byte, with SRS powers computed on the CPU
+        g = orc.srs_powers(tau, synth.to_mont([1])[0], 0, 4 * n + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+        assert np.array_equal(pk.ctx.srs_read(0, 0, 4 * n + 1), g) and np.array_equal(pk.ctx.srs_read(1, 0, 3), gg)
+        rc, want, ch, _ = orc.prove(g, gg, own, tables["witness_flat"], tables["sigma"], log_n, blinds, synth.to_mont([chal_int])[0])
         assert rc == 0 and res.proof_bytes == want and np.array_equal(ch, res.challenges)
     inputs.close()
     pk.close()
@@ -229,6 +235,8 @@ def test_stress_ntt_2p24_coset_round_trip(orc, log_n):
     for k in (0, 1, 0xABCDEF % n, n - 1):
         x = synth.to_mont([5 * pow(w, k, r) % r])[0]
         assert np.array_equal(vals[k], orc.poly_eval(a, x)), k
+    if log_n == 24:   # every one of the 2^24 outputs against the oracle's transform (the s_sigma size of a 2^22-gate proof)
+        assert np.array_equal(vals, orc.ntt(a, coset=g5))
     ctx.ntt_dev(d, log_n, inverse=True, coset=g5)
     back = ctx.download(d, (n, 4))
     assert np.array_equal(back, a)
