@@ -177,6 +177,16 @@ int32_t plk_kzg_open_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, con
 int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int32_t* ticket);
 int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out_xy[8], int32_t* out_is_inf);
 int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+/* The same evaluation for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  The block sums and carries the kernels exchange live in a fixed array
+ * in device memory (524,608 bytes per GPU, held until the process ends) instead of the context's grow-on-demand buffer: the call
+ * performs no hipMalloc / hipFree, at any length up to PLK_POLY_EVAL_STATIC_MAX_LEN coefficients (longer: PLK_ERR_INVALID_ARG).
+ * out_dev: 32 bytes of device memory that receive the value.  The work is enqueued on the context's stream and not waited for:
+ * it is ordered before every later call on this context (plk_sync or plk_download waits).  All contexts of one GPU share the
+ * array: calls that overlap on one GPU race. */
+#define PLK_POLY_EVAL_STATIC_MAX_LEN (1ull << 26)
+int32_t plk_poly_eval_dev_static(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], void* out_dev);
+
                            const uint64_t challenge[4], int32_t* ticket);
 int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]);
 /* Tells the library that the batch of tickets begun so far is complete.  The last stage of every MSM (bucket reduction and

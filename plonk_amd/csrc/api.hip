@@ -155,6 +155,12 @@ extern "C" int32_t plk_create(int32_t device, plk_ctx** out) {
         delete ctx;
         return PLK_ERR_HIP;
     }
+    if (static_scratch_init(ctx) != PLK_OK) {
+        hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
+        streams_release(ctx);
+        delete ctx;
+        return PLK_ERR_HIP;
+    }
     *out = ctx;
     return PLK_OK;
 }

@@ -24,5 +24,7 @@ void ntt_release(plk_ctx* ctx);
 int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs_dev, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
                          uint32_t* q_out, uint32_t* h0_out, uint32_t* work, uint64_t q_first, uint64_t q_count);
 uint64_t division_work_words(uint64_t len);
+// asks the device for the address of the fixed scratch array behind plk_poly_eval_dev_static (once per device; called by plk_create)
+int32_t static_scratch_init(plk_ctx* ctx);
 
 }  // namespace plk

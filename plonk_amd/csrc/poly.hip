@@ -7,6 +7,7 @@
 #include "host_math.hpp"
 #include "kernels.h"
 #include <algorithm>
+#include <mutex>
 
 namespace plk {
 
@@ -540,6 +541,49 @@ extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witnes
                                                 const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev);
 extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
                                          const uint64_t gamma[4], void* z_coeffs_out_dev) {
+// ---- evaluation for callers that cannot allocate ---------------------------------------------------
+// plk_poly_eval_dev needs per-block sums and carries between its kernels (division_work_words(len) words); it takes them from the
+// context's grow-on-demand buffer.  The variant below takes them from a fixed array in device memory instead, so that it never
+// calls hipMalloc / hipFree.  Every GPU the library runs on holds its own copy of the array at its own address until the process
+// ends; `scratch` itself is only a host-side handle (not a device address), so the address is asked for once per device, with
+// that device current, and kept.  The kernels overwrite every word they later read (k_div_sums writes all nb block sums before
+// k_div_carries reads them), so nothing has to be cleared between calls; two calls that overlap on one GPU would share the
+// array and race.
+constexpr uint64_t EVAL_STATIC_MAX_LEN = PLK_POLY_EVAL_STATIC_MAX_LEN;
+constexpr uint64_t EVAL_STATIC_WORDS = 2 * (EVAL_STATIC_MAX_LEN / plk::DIV_BLOCK + 1) * 8 + 64;   // = division_work_words(EVAL_STATIC_MAX_LEN): 524,608 bytes
+static __device__ __align__(256) uint32_t scratch[EVAL_STATIC_WORDS];
+namespace {
+constexpr int STATIC_MAX_DEVICES = 64;
+std::mutex g_static_mutex;
+uint32_t* g_static_ptr[STATIC_MAX_DEVICES] = {};
+}  // namespace
+namespace plk {
+int32_t static_scratch_init(plk_ctx* ctx) {
+    if (ctx->device < 0 || ctx->device >= STATIC_MAX_DEVICES) { ctx->err = "device index beyond the static scratch table"; return PLK_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (g_static_ptr[ctx->device]) return PLK_OK;
+    PLK_HIP(hipSetDevice(ctx->device));
+    void* p = nullptr;
+    PLK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) { ctx->err = "hipGetSymbolAddress returned no address for the static scratch"; return PLK_ERR_HIP; }
+    g_static_ptr[ctx->device] = (uint32_t*)p;
+    return PLK_OK;
+}
+}  // namespace plk
+extern "C" int32_t plk_poly_eval_dev_static(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], void* out_dev) {
+    if (!ctx || !x || !out_dev || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
+    if (len > EVAL_STATIC_MAX_LEN) { ctx->err = "plk_poly_eval_dev_static: more than PLK_POLY_EVAL_STATIC_MAX_LEN coefficients"; return PLK_ERR_INVALID_ARG; }
+    uint32_t* work = ctx->device >= 0 && ctx->device < STATIC_MAX_DEVICES ? g_static_ptr[ctx->device] : nullptr;
+    if (!work) { ctx->err = "plk_poly_eval_dev_static: static scratch of this device was not set up"; return PLK_ERR_HIP; }
+    if (division_work_words(len) > EVAL_STATIC_WORDS) { ctx->err = "plk_poly_eval_dev_static: work area exceeds the static scratch"; return PLK_ERR_INVALID_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    const int profiling = ctx->profiling;
+    ctx->profiling = 0;                       // profiling brackets create events: not on this path
+    const int32_t rc = division_enqueue(ctx, ctx->stream, (const uint32_t*)coeffs_dev, len, x, nullptr, nullptr, (uint32_t*)out_dev, work, 0, 0);
+    ctx->profiling = profiling;
+    return rc;
+}
+
     return plk_grand_product_values_dev(ctx, witness_flat_dev, sigma_dev, log_n, beta, gamma, nullptr, z_coeffs_out_dev);
 }
 extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],

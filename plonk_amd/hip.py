@@ -24,7 +24,7 @@ EXPORTS = [
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
-    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev",
+    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
     "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
@@ -285,6 +285,10 @@ class Context:
         c = _fr(coeffs); out = np.empty(4, dtype=np.uint64)
         self._ck(self.lib.plk_poly_eval(self.h, _ptr(c) if len(c) else None, C.c_uint64(len(c)), _ptr(_fr(x, (4,))), _ptr(out)))
         return out
+
+    def poly_eval_dev_static(self, d_coeffs, length, x, d_out):
+        """plk_poly_eval_dev_static: the value goes to the 32 bytes of device memory at d_out; enqueued, not waited for"""
+        self._ck(self.lib.plk_poly_eval_dev_static(self.h, _vp(d_coeffs), C.c_uint64(length), _ptr(_fr(x, (4,))), _vp(d_out)))
 
     def poly_eval_dev(self, d_coeffs, length, x):
         out = np.empty(4, dtype=np.uint64)
