@@ -139,6 +139,24 @@ int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void*
                          const void* q_mul_vals, const void* z_vals, const void* sigma, uint32_t log_n,
                          const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev, uint64_t* t_len);
 
+/* The same with the public-input polynomial of Circuit::build_public_input_poly (src/circuit.rs:410-439), which the prover's own
+ * temporary circuit never has (src/prover.rs:224-227) but a caller of build_quotient_polynomial on a circuit with marked public
+ * inputs does:  constraint[pi_rows[k]] = alpha * (a[pi_rows[k]] - pi_values[k])  for k = 0 .. pi_count - 1 in that order (a later
+ * entry for the same row replaces an earlier one, as the reference's assignment does), zero elsewhere; its interpolant is added to
+ * the numerator.  pi_rows[k] is the first gate row in which public variable k appears as an input or output (src/circuit.rs:424-429;
+ * resolved by the caller, who holds the builder; a variable that appears in no gate is left out, as the reference skips it), pi_values[k]
+ * its value.  pi_rows / pi_values are host arrays in both forms.  A row >= n gives PLK_ERR_INDEX_OUT_OF_RANGE (the reference would index
+ * out of bounds).  Since a[row] is the row's first wire, the term vanishes only when that wire carries the public value; otherwise the
+ * call returns PLK_ERR_NOT_DIVISIBLE exactly where the reference's assert fires.  pi_count = 0 is plk_quotient. */
+int32_t plk_quotient_pi(plk_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* q_add_vals,
+                        const uint64_t* q_mul_vals, const uint64_t* z_vals, const uint64_t* sigma, uint32_t log_n,
+                        const uint64_t beta[4], const uint64_t gamma[4], const uint64_t alpha[4], const uint64_t* pi_rows,
+                        const uint64_t* pi_values, uint64_t pi_count, uint64_t* t_out_host, uint64_t* t_len);
+int32_t plk_quotient_pi_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals,
+                            const void* q_mul_vals, const void* z_vals, const void* sigma, uint32_t log_n,
+                            const uint64_t beta[4], const uint64_t gamma[4], const uint64_t alpha[4], const uint64_t* pi_rows_host,
+                            const uint64_t* pi_values_host, uint64_t pi_count, void* t_out_dev, uint64_t* t_len);
+
 /* ---- quotient on the extended coset.  No counterpart in the reference, which evaluates its constraints on H only and therefore
  * always obtains t = 0 (src/circuit.rs:442-489); this is the same constraint system taken as polynomial identities, the form a
  * prover with a non-trivial quotient needs.  With a, b, c, q_add, q_mul, z the degree < n interpolants of the given values on H,
@@ -159,6 +177,16 @@ int32_t plk_quotient_coset_dev(plk_ctx* ctx, const void* a, const void* b, const
 int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t x[4], uint64_t out[4]);
 int32_t plk_poly_eval_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], uint64_t out[4]);
 
+/* The same evaluation for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  The block sums and carries the kernels exchange live in a fixed array
+ * in device memory (524,608 bytes per GPU, held until the process ends) instead of the context's grow-on-demand buffer: the call
+ * performs no hipMalloc / hipFree, at any length up to PLK_POLY_EVAL_STATIC_MAX_LEN coefficients (longer: PLK_ERR_INVALID_ARG).
+ * out_dev: 32 bytes of device memory that receive the value.  The work is enqueued on the context's stream and not waited for:
+ * it is ordered before every later call on this context (plk_sync or plk_download waits).  All contexts of one GPU share the
+ * array: calls that overlap on one GPU race. */
+#define PLK_POLY_EVAL_STATIC_MAX_LEN (1ull << 26)
+int32_t plk_poly_eval_dev_static(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], void* out_dev);
+
 /* ---- PCS::commit with hiding bound 1 (ark-poly-commit kzg10::commit; src/prover.rs:150-156,210,253):
  * C = sum coeffs[i] powers_of_g[i] + sum_{j<3} blind[j] powers_of_gamma_g[j].  blind = 12 limbs. */
 int32_t plk_kzg_commit(plk_ctx* ctx, const uint64_t* coeffs_host, uint64_t len, const uint64_t* blind, uint64_t out_xy[8], int32_t* out_is_inf);
@@ -177,16 +205,6 @@ int32_t plk_kzg_open_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, con
 int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int32_t* ticket);
 int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out_xy[8], int32_t* out_is_inf);
 int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
-/* The same evaluation for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  No counterpart in the reference.  The block sums and carries the kernels exchange live in a fixed array
- * in device memory (524,608 bytes per GPU, held until the process ends) instead of the context's grow-on-demand buffer: the call
- * performs no hipMalloc / hipFree, at any length up to PLK_POLY_EVAL_STATIC_MAX_LEN coefficients (longer: PLK_ERR_INVALID_ARG).
- * out_dev: 32 bytes of device memory that receive the value.  The work is enqueued on the context's stream and not waited for:
- * it is ordered before every later call on this context (plk_sync or plk_download waits).  All contexts of one GPU share the
- * array: calls that overlap on one GPU race. */
-#define PLK_POLY_EVAL_STATIC_MAX_LEN (1ull << 26)
-int32_t plk_poly_eval_dev_static(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t x[4], void* out_dev);
-
                            const uint64_t challenge[4], int32_t* ticket);
 int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]);
 /* Tells the library that the batch of tickets begun so far is complete.  The last stage of every MSM (bucket reduction and

@@ -174,6 +174,9 @@ static void store_aff(const Aff& a, uint64_t* xy, int32_t* is_inf) {
     *is_inf = a.inf ? 1 : 0;
 }
 
+// Threads the MSM may use: 1 (the default) is the reference's arkworks build (no `parallel` feature, Cargo.toml:9-18); more is only
+// for the all-cores figure of the CPU baseline (orc_set_threads).
+static int g_threads = 1;
 // Variable-base MSM: signed-digit windows + bucket method (ark-ec VariableBaseMSM, restated).
 static Jac msm_pippenger(const Fr* scalars, const uint64_t* bases_xy, size_t n) {
     if (n == 0) return jac_inf();
@@ -198,6 +201,37 @@ static Jac msm_pippenger(const Fr* scalars, const uint64_t* bases_xy, size_t n) 
         }
     }
     std::vector<Jac> wsum(nwin);
+    if (g_threads > 1 && n >= 4096) {
+        // All-cores form for the CPU baseline: (window, point range) tasks with a bucket array each, dealt to the threads; the
+        // partial window sums of the ranges are added afterwards.  Same digits, same buckets, same result as the serial loop below.
+        const int nchunk = std::max(1, (4 * g_threads + nwin - 1) / nwin);
+        const size_t per = (n + nchunk - 1) / nchunk;
+        std::vector<Jac> part((size_t)nwin * nchunk);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+        for (int task = 0; task < nwin * nchunk; ++task) {
+            const int w = task / nchunk, ch = task % nchunk;
+            const size_t lo = (size_t)ch * per, hi = std::min(n, lo + per);
+            std::vector<Jac> bk(half, jac_inf());
+            for (size_t i = lo; i < hi; ++i) {
+                int32_t d = digits[i * nwin + w];
+                if (d == 0) continue;
+                Aff p = load_aff(bases_xy + 8 * i, 0);
+                if (d > 0) bk[d - 1] = jac_add_mixed(bk[d - 1], p);
+                else bk[-d - 1] = jac_add_mixed(bk[-d - 1], aff_neg(p));
+            }
+            Jac run = jac_inf(), acc = jac_inf();
+            for (size_t b = half; b-- > 0;) { run = jac_add(run, bk[b]); acc = jac_add(acc, run); }
+            part[task] = acc;
+        }
+        for (int w = 0; w < nwin; ++w) {
+            Jac acc = jac_inf();
+            for (int ch = 0; ch < nchunk; ++ch) acc = jac_add(acc, part[(size_t)w * nchunk + ch]);
+            wsum[w] = acc;
+        }
+        Jac total = wsum[nwin - 1];
+        for (int w = nwin - 2; w >= 0; --w) { for (int j = 0; j < c; ++j) total = jac_dbl(total); total = jac_add(total, wsum[w]); }
+        return total;
+    }
     std::vector<Jac> buckets(half);
     for (int w = 0; w < nwin; ++w) {
         for (auto& b : buckets) b = jac_inf();
@@ -381,10 +415,17 @@ static void grand_product_values(const Fr* wflat, const uint64_t* sigma, size_t 
     for (size_t i = 0; i + 1 < n; ++i) z[i + 1] = mul(mul(z[i], num[i]), den[i]);
 }
 // src/circuit.rs:446-453 + 343-379 summed pointwise; returns 0 on success, 1 if t(X) is not divisible by Z_H(X)
+// Public inputs (src/circuit.rs:410-439): constraint[pi_rows[k]] = alpha * (a[pi_rows[k]] - pi_values[k]) in the order of the list (assignment: a
+// later entry for the same row replaces an earlier one), interpolated and added to the numerator.  pi_count = 0 is what the prover reaches.
 static int quotient(const Fr* a, const Fr* b, const Fr* c, const Fr* qa, const Fr* qm, const Fr* zv, const uint64_t* sigma, int log_n,
-                    const Fr& beta, const Fr& gamma, std::vector<Fr>& t_out) {
+                    const Fr& beta, const Fr& gamma, std::vector<Fr>& t_out, const Fr* alpha = nullptr, const uint64_t* pi_rows = nullptr,
+                    const Fr* pi_values = nullptr, size_t pi_count = 0) {
     const size_t n = (size_t)1 << log_n;
-    std::vector<Fr> gate(n), perm(n);
+    std::vector<Fr> gate(n), perm(n), pub(n);
+    for (size_t k = 0; k < pi_count; ++k) {
+        if (pi_rows[k] >= n) return 2;                                    // the reference indexes out of bounds
+        pub[pi_rows[k]] = mul(*alpha, sub(a[pi_rows[k]], pi_values[k]));   // src/circuit.rs:432
+    }
     for (size_t i = 0; i < n; ++i) {
         gate[i] = add(mul(qa[i], sub(add(a[i], b[i]), c[i])), mul(qm[i], sub(mul(a[i], b[i]), c[i])));
         const Fr w[3] = {a[i], b[i], c[i]};
@@ -398,7 +439,8 @@ static int quotient(const Fr* a, const Fr* b, const Fr* c, const Fr* qa, const F
     }
     ntt_inplace(gate.data(), log_n, true, nullptr);
     ntt_inplace(perm.data(), log_n, true, nullptr);
-    for (size_t i = 0; i < n; ++i) gate[i] = add(gate[i], perm[i]);       // + pub_poly, which is zero (src/prover.rs:224-227)
+    ntt_inplace(pub.data(), log_n, true, nullptr);                          // src/circuit.rs:438 (all zero in the prover, src/prover.rs:224-227)
+    for (size_t i = 0; i < n; ++i) gate[i] = add(add(gate[i], perm[i]), pub[i]);   // src/circuit.rs:469
     size_t len = trimmed_len(gate.data(), n);
     // divide_by_vanishing_poly: degree < n, so the quotient is zero and the remainder is the numerator itself
     t_out.clear();
@@ -410,6 +452,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // ------------------------------------------------------------------------------------- C ABI for the ctypes wrapper
 extern "C" {
 
+int orc_set_threads(int t) { const int old = g_threads; g_threads = t < 1 ? 1 : t; return old; }
 void orc_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n) {
     for (uint64_t i = 0; i < n; ++i) {
         Fr x, y, r; memcpy(x.v, a + 4 * i, 32); if (b) memcpy(y.v, b + 4 * i, 32);
@@ -490,6 +533,12 @@ int orc_quotient(const uint64_t* a, const uint64_t* b, const uint64_t* c, const 
                  int log_n, const uint64_t* beta, const uint64_t* gamma) {
     Fr be, ga; memcpy(be.v, beta, 32); memcpy(ga.v, gamma, 32); std::vector<Fr> t;
     return quotient((const Fr*)a, (const Fr*)b, (const Fr*)c, (const Fr*)qa, (const Fr*)qm, (const Fr*)zv, sigma, log_n, be, ga, t);
+}
+// the same with public inputs (src/circuit.rs:410-439); returns 2 for a row outside the domain
+int orc_quotient_pi(const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* qa, const uint64_t* qm, const uint64_t* zv, const uint64_t* sigma,
+                    int log_n, const uint64_t* beta, const uint64_t* gamma, const uint64_t* alpha, const uint64_t* pi_rows, const uint64_t* pi_values, uint64_t pi_count) {
+    Fr be, ga, al; memcpy(be.v, beta, 32); memcpy(ga.v, gamma, 32); memcpy(al.v, alpha, 32); std::vector<Fr> t;
+    return quotient((const Fr*)a, (const Fr*)b, (const Fr*)c, (const Fr*)qa, (const Fr*)qm, (const Fr*)zv, sigma, log_n, be, ga, t, &al, pi_rows, (const Fr*)pi_values, pi_count);
 }
 // Quotient of the reference's constraint system on polynomials, as plk_quotient_coset defines it (no counterpart in the reference,
 // which never leaves H: src/circuit.rs:442-489).  With a, b, c, q_add, q_mul, z the degree < n interpolants of the column values,

@@ -111,6 +111,11 @@ def point_to_ints(xy, inf):
 OPS = {"add": 0, "sub": 1, "mul": 2, "inv": 3, "neg": 4}
 
 
+def set_threads(t: int) -> int:
+    """threads of the MSM (1 = the reference's single-threaded arkworks build); returns the previous setting"""
+    return int(lib().orc_set_threads(C.c_int(t)))
+
+
 def fr_op(op, a, b=None):
     a = _u64(a); out = np.empty_like(a)
     lib().orc_fr_op(OPS[op], _p(a), _p(_u64(b)) if b is not None else None, _p(out), C.c_uint64(a.size // 4))
@@ -189,6 +194,15 @@ def quotient(a, b, c, qa, qm, zv, sigma, beta, gamma) -> int:
     a = _u64(a).reshape(-1, 4); n = len(a); log_n = (n - 1).bit_length()
     return lib().orc_quotient(_p(a), _p(_u64(b)), _p(_u64(c)), _p(_u64(qa)), _p(_u64(qm)), _p(_u64(zv)), _p(_u64(sigma)), log_n,
                               _p(_u64(beta)), _p(_u64(gamma)))
+
+
+def quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, pi_rows, pi_values) -> int:
+    """build_quotient_polynomial with the public-input polynomial of src/circuit.rs:410-439: 0 divisible, 1 not, 2 row outside the domain"""
+    a = _u64(a).reshape(-1, 4); n = len(a); log_n = (n - 1).bit_length()
+    rows = np.ascontiguousarray(pi_rows, dtype=np.uint64); vals = _u64(pi_values).reshape(-1, 4)
+    assert len(rows) == len(vals)
+    return lib().orc_quotient_pi(_p(a), _p(_u64(b)), _p(_u64(c)), _p(_u64(qa)), _p(_u64(qm)), _p(_u64(zv)), _p(_u64(sigma)), log_n,
+                                 _p(_u64(beta)), _p(_u64(gamma)), _p(_u64(alpha)), _p(rows), _p(vals), C.c_uint64(len(rows)))
 
 
 def quotient_coset(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha):

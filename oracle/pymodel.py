@@ -548,17 +548,27 @@ def permutation_constraint_values(a_col, b_col, c_col, z_vals, sigma, n, beta, g
     return out
 
 
+def public_input_values(a_col, n, alpha, pi_rows, pi_values):
+    """src/circuit.rs:419-436: constraint[row] = alpha * (a_vals[row] - pi_value), assigned in the order of the public inputs (a later
+    one on the same row replaces an earlier one); pi_rows[k] is the first gate row that uses public variable k (:424-429)."""
+    out = [0] * n
+    for row, v in zip(pi_rows, pi_values):
+        out[row] = alpha * (a_col[row] - v) % R_MOD
+    return out
+
+
 class NotDivisible(Exception):
     pass
 
 
-def build_quotient(a_col, b_col, c_col, qa_vals, qm_vals, z_vals, sigma, n, beta, gamma):
-    """src/circuit.rs:442-489 with no public inputs (src/prover.rs:224-227)."""
+def build_quotient(a_col, b_col, c_col, qa_vals, qm_vals, z_vals, sigma, n, beta, gamma, alpha=0, pi_rows=(), pi_values=()):
+    """src/circuit.rs:442-489; the prover reaches it with no public inputs (src/prover.rs:224-227)."""
     gate_poly = trim(ntt(gate_values(a_col, b_col, c_col, qa_vals, qm_vals), n, inverse=True))
     perm_poly = trim(ntt(permutation_constraint_values(a_col, b_col, c_col, z_vals, sigma, n, beta, gamma), n, inverse=True))
-    m = max(len(gate_poly), len(perm_poly))
-    t_num = trim([((gate_poly[i] if i < len(gate_poly) else 0) + (perm_poly[i] if i < len(perm_poly) else 0)) % R_MOD
-                  for i in range(m)])
+    pub_poly = trim(ntt(public_input_values(a_col, n, alpha, pi_rows, pi_values), n, inverse=True))
+    m = max(len(gate_poly), len(perm_poly), len(pub_poly))
+    at = lambda p, i: p[i] if i < len(p) else 0
+    t_num = trim([(at(gate_poly, i) + at(perm_poly, i) + at(pub_poly, i)) % R_MOD for i in range(m)])
     q, r = divide_by_vanishing(t_num, n)
     if r:
         raise NotDivisible("t(X) not divisible by Z_H(X)")

@@ -102,6 +102,7 @@ struct DeviceStreams {
     hipStream_t stream = nullptr, st_sort = nullptr, st_acc[2] = {nullptr, nullptr}, st_red = nullptr;
     int users = 0;
 };
+constexpr size_t MAX_DEVICE_STREAMS = 4;   // hardware queues a process gets per priority level (GPU_MAX_HW_QUEUES)
 std::mutex g_streams_mutex;
 std::map<int, DeviceStreams> g_streams;
 
@@ -120,6 +121,20 @@ bool streams_acquire(plk_ctx* ctx) {
             hipStreamCreateWithFlags(&d.st_red, hipStreamNonBlocking) != hipSuccess)
             return false;
         d.st_sort = d.stream;
+        // The two rules above are enforced, not only written down: whoever adds a stream or a priority gets a refused plk_create
+        // instead of a process that hangs under load.
+        const hipStream_t all[] = {d.stream, d.st_sort, d.st_acc[0], d.st_acc[1], d.st_red};
+        std::vector<hipStream_t> distinct;
+        int prio0 = 0;
+        for (hipStream_t st : all) {
+            if (std::find(distinct.begin(), distinct.end(), st) != distinct.end()) continue;
+            int prio = 0;
+            if (hipStreamGetPriority(st, &prio) != hipSuccess) return false;
+            if (distinct.empty()) prio0 = prio;
+            if (prio != prio0) { fprintf(stderr, "libplonk_hip: streams of different priorities (%d, %d) are not allowed\n", prio0, prio); return false; }
+            distinct.push_back(st);
+        }
+        if (distinct.size() > MAX_DEVICE_STREAMS) { fprintf(stderr, "libplonk_hip: %zu streams per device, at most %zu hardware queues\n", distinct.size(), MAX_DEVICE_STREAMS); return false; }
     }
     ++d.users;
     ctx->stream = d.stream; ctx->st_sort = d.st_sort; ctx->st_acc[0] = d.st_acc[0]; ctx->st_acc[1] = d.st_acc[1]; ctx->st_red = d.st_red;

@@ -383,12 +383,10 @@ __global__ void __launch_bounds__(256) k_quotient_vals(const uint32_t* __restric
         // z lhs / rhs - 1 = (z lhs - rhs) / rhs: zero exactly when the numerator is, so the inversion is only paid on bad witnesses
         const fe l = mul<FrP>(lhs, zi), r = mul<FrP>(rhs, fe_const(FrP::TO_R));
         fe d = sub2<FrP>(l, r); norm(d);
-        if (is_zero_mod<FrP>(d)) perm = fe_zero();
-        else {
-            fe rr = rhs; // 2^261 form, bound 2
-            if (is_zero_mod<FrP>(rr)) { atomicOr(flag, 4u); perm = fe_zero(); }
-            else perm = mul<FrP>(inv<FrP>(rr), d);                     // (1/rhs)*2^261 times d*2^256 -> x*2^256
-        }
+        // rhs = 0 is the reference's inverse().unwrap() panic (src/circuit.rs:377), whatever the numerator is
+        if (is_zero_mod<FrP>(rhs)) { atomicOr(flag, 4u); perm = fe_zero(); }   // rhs: 2^261 form, bound 2
+        else if (is_zero_mod<FrP>(d)) perm = fe_zero();
+        else perm = mul<FrP>(inv<FrP>(rhs), d);                        // (1/rhs)*2^261 times d*2^256 -> x*2^256
     }
     fe v = add(gate, perm);                                            // bound 8
     norm(v);
@@ -396,6 +394,19 @@ __global__ void __launch_bounds__(256) k_quotient_vals(const uint32_t* __restric
     uint32_t wv[8];
     pack(out, wv);
     store8(vals + 8 * i, wv);
+}
+// Public-input term of src/circuit.rs:410-439 added to the numerator values: vals[row_k] += alpha * (a[row_k] - pi_k).
+// The reference assigns constraint[row] per public input, so a later input replaces an earlier one on the same row: the host passes
+// one entry per distinct row (the last one) and the additions do not collide.
+__global__ void __launch_bounds__(256) k_public_input_term(const uint32_t* __restrict__ a, const uint64_t* __restrict__ rows, const uint32_t* __restrict__ pi,
+                                                           uint64_t count, W8 alpha, uint32_t* __restrict__ vals) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const uint64_t row = rows[k];
+    fe d = sub2<FrP>(ld_fe(a + 8 * row), ld_fe(pi + 8 * k)); norm(d);             // bound 3
+    fe v = add(ld_fe(vals + 8 * row), mul<FrP>(to_rp(fe_of(alpha)), d));          // bound 3
+    norm(v);
+    st_fe<FrP>(vals + 8 * row, mul<FrP>(v, fe_const(FrP::ONE)));
 }
 __global__ void __launch_bounds__(256) k_any_nonzero(const uint32_t* __restrict__ data, uint64_t n_words, uint32_t* __restrict__ flag) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -411,8 +422,8 @@ __global__ void __launch_bounds__(256) k_perm_values(const uint64_t* __restrict_
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t n4 = 1ull << log_n4;
     if (i >= n4) return;
-    uint64_t s = i < sigma_len ? sigma[i] : i;
-    if (s >= n4) { atomicOr(flag, 2u); s = 0; }
+    // domain.element(s) is w^s for any s (src/poly_utils.rs:25): an entry beyond the domain wraps around, nothing panics
+    const uint64_t s = (i < sigma_len ? sigma[i] : i) & (n4 - 1);
     const fe to_r = fe_const(FrP::TO_R);
     const uint64_t e[2] = {i, s};
     uint32_t* dst[2] = {vals_id, vals_sigma};
@@ -530,17 +541,6 @@ extern "C" int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint
     return plk_poly_eval_dev(ctx, d.p, len, x, out);
 }
 
-static int32_t read_flag(plk_ctx* ctx, uint32_t* out) {
-    PLK_HIP(hipMemcpyAsync(ctx->flag_host, ctx->flag_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PLK_HIP(hipStreamSynchronize(ctx->stream));
-    *out = *ctx->flag_host;
-    return PLK_OK;
-}
-
-extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
-                                                const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev);
-extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
-                                         const uint64_t gamma[4], void* z_coeffs_out_dev) {
 // ---- evaluation for callers that cannot allocate ---------------------------------------------------
 // plk_poly_eval_dev needs per-block sums and carries between its kernels (division_work_words(len) words); it takes them from the
 // context's grow-on-demand buffer.  The variant below takes them from a fixed array in device memory instead, so that it never
@@ -584,6 +584,17 @@ extern "C" int32_t plk_poly_eval_dev_static(plk_ctx* ctx, const void* coeffs_dev
     return rc;
 }
 
+static int32_t read_flag(plk_ctx* ctx, uint32_t* out) {
+    PLK_HIP(hipMemcpyAsync(ctx->flag_host, ctx->flag_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PLK_HIP(hipStreamSynchronize(ctx->stream));
+    *out = *ctx->flag_host;
+    return PLK_OK;
+}
+
+extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
+                                                const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev);
+extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
+                                         const uint64_t gamma[4], void* z_coeffs_out_dev) {
     return plk_grand_product_values_dev(ctx, witness_flat_dev, sigma_dev, log_n, beta, gamma, nullptr, z_coeffs_out_dev);
 }
 extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
@@ -638,23 +649,46 @@ extern "C" int32_t plk_grand_product(plk_ctx* ctx, const uint64_t* witness_flat_
     return PLK_OK;
 }
 
-extern "C" int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
-                                    const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev,
-                                    uint64_t* t_len) {
+extern "C" int32_t plk_quotient_pi_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                                       const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                                       const uint64_t alpha[4], const uint64_t* pi_rows_host, const uint64_t* pi_values_host, uint64_t pi_count,
+                                       void* t_out_dev, uint64_t* t_len) {
     if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !beta || !gamma || !t_out_dev || !t_len || log_n > 26)
         return PLK_ERR_INVALID_ARG;
+    if (pi_count && (!alpha || !pi_rows_host || !pi_values_host)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
     hipStream_t st = ctx->stream;
     uint32_t* t = (uint32_t*)t_out_dev;
+    // public inputs: one entry per distinct row, the last assignment wins (src/circuit.rs:432 assigns, it does not add)
+    std::vector<uint64_t> rows, vals;
+    if (pi_count) {
+        std::map<uint64_t, uint64_t> last;
+        for (uint64_t k = 0; k < pi_count; ++k) {
+            if (pi_rows_host[k] >= n) { ctx->err = "public input row outside the domain"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
+            last[pi_rows_host[k]] = k;
+        }
+        for (const auto& e : last) {
+            rows.push_back(e.first);
+            vals.insert(vals.end(), pi_values_host + 4 * e.second, pi_values_host + 4 * e.second + 4);
+        }
+    }
+    DevBuf rows_dev, vals_dev;
+    if (!rows.empty()) {
+        PLK_HIP(rows_dev.alloc_copy(rows.data(), rows.size() * 8));
+        PLK_HIP(vals_dev.alloc_copy(vals.data(), vals.size() * 8));
+    }
     PLK_HIP(hipMemsetAsync(ctx->flag_dev, 0, 4, st));
     prof_begin(ctx, st, "pointwise");
     hipLaunchKernelGGL(k_quotient_vals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)c,
                        (const uint32_t*)q_add_vals, (const uint32_t*)q_mul_vals, (const uint32_t*)z_vals, (const uint64_t*)sigma, n, w8_of(beta), w8_of(gamma), t,
                        ctx->flag_dev);
+    if (!rows.empty())
+        hipLaunchKernelGGL(k_public_input_term, dim3((unsigned)((rows.size() + 255) / 256)), dim3(256), 0, st, (const uint32_t*)a, (const uint64_t*)rows_dev.p,
+                           (const uint32_t*)vals_dev.p, (uint64_t)rows.size(), w8_of(alpha), t);
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
-    // numerator in coefficient form: ifft(gate) + ifft(perm) + ifft(0) = ifft(gate + perm)
+    // numerator in coefficient form: ifft(gate) + ifft(perm) + ifft(pub) = ifft(gate + perm + pub)
     PLK_TRY(ntt_run(ctx, st, t, log_n, true, nullptr));
     // divide_by_vanishing_poly on a numerator of degree < n: quotient 0, remainder = the numerator, which must vanish
     hipLaunchKernelGGL(k_any_nonzero, dim3(256), dim3(256), 0, st, t, n * 8, ctx->flag_dev);
@@ -667,9 +701,20 @@ extern "C" int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, 
     *t_len = 0;
     return PLK_OK;
 }
+extern "C" int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                                    const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev,
+                                    uint64_t* t_len) {
+    return plk_quotient_pi_dev(ctx, a, b, c, q_add_vals, q_mul_vals, z_vals, sigma, log_n, beta, gamma, nullptr, nullptr, nullptr, 0, t_out_dev, t_len);
+}
 extern "C" int32_t plk_quotient(plk_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* q_add_vals, const uint64_t* q_mul_vals,
                                 const uint64_t* z_vals, const uint64_t* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
                                 uint64_t* t_out_host, uint64_t* t_len) {
+    return plk_quotient_pi(ctx, a, b, c, q_add_vals, q_mul_vals, z_vals, sigma, log_n, beta, gamma, nullptr, nullptr, nullptr, 0, t_out_host, t_len);
+}
+extern "C" int32_t plk_quotient_pi(plk_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* q_add_vals, const uint64_t* q_mul_vals,
+                                   const uint64_t* z_vals, const uint64_t* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                                   const uint64_t alpha[4], const uint64_t* pi_rows, const uint64_t* pi_values, uint64_t pi_count, uint64_t* t_out_host,
+                                   uint64_t* t_len) {
     if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !t_out_host || log_n > 26) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
@@ -678,7 +723,7 @@ extern "C" int32_t plk_quotient(plk_ctx* ctx, const uint64_t* a, const uint64_t*
     for (int i = 0; i < 6; ++i) PLK_HIP(d[i].alloc_copy(src[i], n * 32));
     PLK_HIP(s.alloc_copy(sigma, 3 * n * 8));
     PLK_HIP(t.alloc(n * 32));
-    PLK_TRY(plk_quotient_dev(ctx, d[0].p, d[1].p, d[2].p, d[3].p, d[4].p, d[5].p, s.p, log_n, beta, gamma, t.p, t_len));
+    PLK_TRY(plk_quotient_pi_dev(ctx, d[0].p, d[1].p, d[2].p, d[3].p, d[4].p, d[5].p, s.p, log_n, beta, gamma, alpha, pi_rows, pi_values, pi_count, t.p, t_len));
     PLK_HIP(hipMemcpy(t_out_host, t.p, n * 32, hipMemcpyDeviceToHost));
     return PLK_OK;
 }
@@ -701,7 +746,7 @@ extern "C" int32_t plk_interpolate_permutation_dev(plk_ctx* ctx, const void* sig
     uint32_t flag;
     PLK_TRY(read_flag(ctx, &flag));
     prof_collect(ctx, false);
-    if (flag & 2u) { ctx->err = "sigma entry outside the permutation domain"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
+    (void)flag;
     return PLK_OK;
 }
 extern "C" int32_t plk_interpolate_permutation(plk_ctx* ctx, const uint64_t* sigma_host, uint64_t sigma_len, uint32_t log_n4, uint64_t* s_id_out_host,

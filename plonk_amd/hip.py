@@ -24,7 +24,7 @@ EXPORTS = [
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
-    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
+    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
     "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
@@ -259,6 +259,16 @@ class Context:
         self._ck(self.lib.plk_quotient(self.h, _ptr(a), _ptr(_fr(b)), _ptr(_fr(c)), _ptr(_fr(qa)), _ptr(_fr(qm)), _ptr(_fr(zv)),
                                        _ptr(np.ascontiguousarray(sigma, dtype=np.uint64)), C.c_uint32(log_n), _ptr(_fr(beta, (4,))),
                                        _ptr(_fr(gamma, (4,))), _ptr(out), C.byref(tlen)))
+        return out, tlen.value
+
+    def quotient_pi(self, a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, pi_rows, pi_values):
+        """plk_quotient_pi: build_quotient_polynomial with public inputs (rows and values, src/circuit.rs:410-439)"""
+        a = _fr(a); n = len(a); log_n = (n - 1).bit_length()
+        rows = np.ascontiguousarray(pi_rows, dtype=np.uint64); vals = _fr(pi_values)
+        out = np.empty((n, 4), dtype=np.uint64); tlen = C.c_uint64(0)
+        self._ck(self.lib.plk_quotient_pi(self.h, _ptr(a), _ptr(_fr(b)), _ptr(_fr(c)), _ptr(_fr(qa)), _ptr(_fr(qm)), _ptr(_fr(zv)),
+                                          _ptr(np.ascontiguousarray(sigma, dtype=np.uint64)), C.c_uint32(log_n), _ptr(_fr(beta, (4,))),
+                                          _ptr(_fr(gamma, (4,))), _ptr(_fr(alpha, (4,))), _ptr(rows), _ptr(vals), C.c_uint64(len(rows)), _ptr(out), C.byref(tlen)))
         return out, tlen.value
 
     def quotient_dev(self, d_a, d_b, d_c, d_qa, d_qm, d_zv, d_sigma, log_n, beta, gamma, d_t):

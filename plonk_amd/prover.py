@@ -9,6 +9,7 @@ There is no CPU path: a missing library or GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 from dataclasses import dataclass
 
@@ -66,6 +67,7 @@ class ProofResult:
 class DeviceInputs:
     def __init__(self, pk, handle, log_n, polys):
         self.pk, self.h, self.log_n, self.polys = pk, handle, log_n, polys
+        pk._inputs.add(self)          # the key closes its inputs before its context goes away (their buffers are freed through it)
 
     def close(self):
         if self.h:
@@ -167,6 +169,7 @@ class ProverKey:
         self._ck(self.lib.plonk_pk_create(C.c_int32(device), C.byref(h)))
         self.h = h
         self._cb = None
+        self._inputs = weakref.WeakSet()
         # the same plk_ctx seen through the raw C ABI
         self.ctx = hip.Context.__new__(hip.Context)
         self.ctx.lib = hip.load_library()
@@ -178,6 +181,8 @@ class ProverKey:
 
     def close(self):
         if getattr(self, "h", None):
+            for inp in list(self._inputs):     # device buffers of the inputs belong to this key's context: release them first
+                inp.close()
             self.ctx.h = None
             self.lib.plonk_pk_destroy(self.h)
             self.h = None

@@ -186,6 +186,52 @@ def test_quotient_on_the_extended_coset(ctx, orc, log_n, coset):
         assert orc.quotient_coset(a, b, bad, qa, qm, zv, sigma, beta, gamma, alpha)[0] == 1
 
 
+@pytest.mark.parametrize("log_n", [2, 5, 10])
+def test_quotient_with_public_inputs(ctx, orc, log_n):
+    """Circuit::build_public_input_poly inside build_quotient_polynomial (src/circuit.rs:410-439, :458, :469): the term
+    alpha * (a[row] - pi) is zero exactly when the row's first wire carries the public value; any other value trips the
+    reference's divisibility assert (:487).  Same verdicts as the oracle for matching, mismatching and overwritten entries."""
+    from plonk_amd.hip import PlonkHipError
+    inp = _circuit(orc, log_n, 17 + log_n)
+    n = inp["n"]
+    w = orc.fr_from_ints(inp["witness_flat"]); sigma = np.array(inp["sigma"], dtype=np.uint64)
+    beta, gamma, alpha = rand_fr(orc, 3, 91 + log_n)
+    zv, _ = orc.grand_product(w, sigma, beta, gamma)
+    a, b, c, qa, qm = (orc.fr_from_ints(col) for col in inp["cols"])
+    rows = np.array([0, n - 1, n // 2], dtype=np.uint64)
+    good = a[rows.astype(np.int64)]
+    # public values that equal the wires they are compared with: the quotient is the zero polynomial, as without public inputs
+    assert orc.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows, good) == 0
+    t, tlen = ctx.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows, good)
+    assert tlen == 0 and not t.any()
+    # one value off by one: not divisible, on both sides
+    bad = good.copy(); bad[1] = orc.fr_op("add", bad[1:2], orc.fr_from_ints([1]))[0]
+    assert orc.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows, bad) == 1
+    with pytest.raises(PlonkHipError) as e:
+        ctx.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows, bad)
+    assert e.value.status == "PLK_ERR_NOT_DIVISIBLE"
+    # the wrong entry is replaced by a later, matching entry for the same row (the reference assigns constraint[row])
+    rows2 = np.concatenate([rows, rows[1:2]]); vals2 = np.concatenate([bad, good[1:2]])
+    assert orc.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows2, vals2) == 0
+    t, tlen = ctx.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows2, vals2)
+    assert tlen == 0 and not t.any()
+    # ... and the other way round
+    rows3 = np.concatenate([rows, rows[1:2]]); vals3 = np.concatenate([good, bad[1:2]])
+    assert orc.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows3, vals3) == 1
+    with pytest.raises(PlonkHipError) as e:
+        ctx.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, rows3, vals3)
+    assert e.value.status == "PLK_ERR_NOT_DIVISIBLE"
+    # alpha = 0 switches the term off whatever the values are
+    zero = orc.fr_from_ints([0])[0]
+    assert orc.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, zero, rows, bad) == 0
+    assert ctx.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, zero, rows, bad)[1] == 0
+    # a row outside the domain is the reference's index panic
+    assert orc.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, [n], good[:1]) == 2
+    with pytest.raises(PlonkHipError) as e:
+        ctx.quotient_pi(a, b, c, qa, qm, zv, sigma, beta, gamma, alpha, [n], good[:1])
+    assert e.value.status == "PLK_ERR_INDEX_OUT_OF_RANGE"
+
+
 def test_interpolate_permutation(ctx, orc):
     inp = _circuit(orc, 4, 5)
     log_n4 = inp["n4"].bit_length() - 1
@@ -290,10 +336,15 @@ def test_failure_behaviour_follows_the_reference(orc):
     with pytest.raises(PlonkHipError) as e:
         c.interpolate_permutation(np.arange(33, dtype=np.uint64), 5)
     assert e.value.status == "PLK_ERR_INVALID_ARG"
-    bad = np.arange(24, dtype=np.uint64); bad[3] = 32
-    with pytest.raises(PlonkHipError) as e:
-        c.interpolate_permutation(bad, 5)
-    assert e.value.status == "PLK_ERR_INDEX_OUT_OF_RANGE"
+    # an entry beyond the domain is not an error: domain.element(i) is w^i for any i (src/poly_utils.rs:25), so 32 + 5 acts as 5
+    wrapped = np.arange(24, dtype=np.uint64); wrapped[3] = 32 + 5
+    inside = np.arange(24, dtype=np.uint64); inside[3] = 5
+    got_id, got_sigma = c.interpolate_permutation(wrapped, 5)
+    want_id, want_sigma = c.interpolate_permutation(inside, 5)
+    assert np.array_equal(got_id, want_id) and np.array_equal(got_sigma, want_sigma)
+    x_poly = np.zeros((32, 4), np.uint64); x_poly[1] = orc.fr_from_ints([1])[0]
+    dom = orc.ntt(x_poly)
+    assert np.array_equal(got_sigma, orc.ntt(dom[np.concatenate([inside, np.arange(24, 32, dtype=np.uint64)]).astype(np.int64)], inverse=True))
 
     # tickets: ending one twice, ending one that was never handed out, more tickets than slots
     d = c.upload(coeffs)

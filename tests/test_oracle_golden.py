@@ -120,6 +120,29 @@ def test_oracle_whole_proof(orc, idx):
     assert pm.trim(orc.fr_to_ints(zc)) == [I(x) for x in p["z_coeffs"]]
 
 
+def test_oracle_all_cores_msm_is_the_same_proof(orc):
+    """The OpenMP form of the oracle's MSM (used only for the all-cores CPU baseline) yields the bytes of the single-threaded proof."""
+    from plonk_amd import synth
+    variables, gates = synth.synthetic_circuit(11, seed=4)
+    tb = synth.circuit_tables(variables, gates)
+    n4 = 4 * tb["n"]
+    tau, gs = synth.seeded_scalars(2, 7)
+    g = orc.srs_powers(tau, synth.to_mont([1])[0], 0, n4 + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+    x_poly = np.zeros((n4, 4), dtype=np.uint64); x_poly[1] = synth.to_mont([1])[0]
+    dom = orc.ntt(x_poly)
+    sig = np.concatenate([np.asarray(tb["sigma"], dtype=np.int64), np.arange(3 * tb["n"], n4, dtype=np.int64)])
+    polys = [synth.trim(tb["a"]), synth.trim(tb["b"]), synth.trim(tb["c"]), synth.trim(orc.ntt(tb["q_add_vals"], inverse=True)),
+             synth.trim(orc.ntt(tb["q_mul_vals"], inverse=True)), synth.to_mont([0, 1]), synth.trim(orc.ntt(dom[sig], inverse=True))]
+    blinds = synth.seeded_scalars(27, 8); chal = synth.to_mont([0x1234567890ABCDEF1122334455667788])[0]
+    rc1, one, ch1, _ = orc.prove(g, gg, polys, tb["witness_flat"], tb["sigma"], tb["log_n"], blinds, chal)
+    assert orc.set_threads(4) == 1
+    try:
+        rc4, four, ch4, _ = orc.prove(g, gg, polys, tb["witness_flat"], tb["sigma"], tb["log_n"], blinds, chal)
+    finally:
+        assert orc.set_threads(1) == 4
+    assert rc1 == 0 and rc4 == 0 and one == four and np.array_equal(ch1, ch4)
+
+
 def test_oracle_rejects_bad_witness(orc):
     v, g = pm.synthetic_circuit(3, seed=3)
     inp = pm.prepare_inputs(v, g)
@@ -130,6 +153,32 @@ def test_oracle_rejects_bad_witness(orc):
     assert orc.quotient(a, b, c, qa, qm, zv, sigma, beta, gamma) == 0
     c[2] = a[0]
     assert orc.quotient(a, b, c, qa, qm, zv, sigma, beta, gamma) == 1
+
+
+def test_oracle_public_input_term(orc):
+    """build_public_input_poly (src/circuit.rs:410-439) in both restatements, on the reference's own example circuit (src/main.rs:29-39)
+    with variable 0 marked public as the commented-out line src/main.rs:40 would: value 3, first used in gate 0, where a = 3."""
+    inp = pm.prepare_inputs(*pm.example_circuit())
+    n = inp["n"]
+    a_col, b_col, c_col, qa, qm = inp["cols"]
+    beta, gamma, alpha = 1234567, 7654321, 424242
+    z_vals, _ = pm.build_grand_product(inp["witness_flat"], inp["sigma"], n, beta, gamma)
+    f = lambda x: orc.fr_from_ints([x])[0]
+    cols = [orc.fr_from_ints(col) for col in inp["cols"]]
+    sigma = np.array(inp["sigma"], dtype=np.uint64)
+    zv = orc.fr_from_ints(z_vals[:n])
+    # matching public value: the term vanishes, t = 0 as without public inputs
+    assert pm.build_quotient(a_col, b_col, c_col, qa, qm, z_vals, inp["sigma"], n, beta, gamma, alpha, [0], [a_col[0]]) == []
+    assert orc.quotient_pi(*cols, zv, sigma, f(beta), f(gamma), f(alpha), [0], orc.fr_from_ints([a_col[0]])) == 0
+    # a public variable whose first use is not the row's first wire (value 4 is b of gate 0, a is 3): alpha * (3 - 4) at row 0
+    assert pm.public_input_values(a_col, n, alpha, [0], [b_col[0]])[0] == alpha * (a_col[0] - b_col[0]) % pm.R_MOD
+    with pytest.raises(pm.NotDivisible):
+        pm.build_quotient(a_col, b_col, c_col, qa, qm, z_vals, inp["sigma"], n, beta, gamma, alpha, [0], [b_col[0]])
+    assert orc.quotient_pi(*cols, zv, sigma, f(beta), f(gamma), f(alpha), [0], orc.fr_from_ints([b_col[0]])) == 1
+    # assignment semantics: the later entry for a row wins
+    assert orc.quotient_pi(*cols, zv, sigma, f(beta), f(gamma), f(alpha), [0, 0], orc.fr_from_ints([b_col[0], a_col[0]])) == 0
+    assert orc.quotient_pi(*cols, zv, sigma, f(beta), f(gamma), f(alpha), [0, 0], orc.fr_from_ints([a_col[0], b_col[0]])) == 1
+    assert orc.quotient_pi(*cols, zv, sigma, f(beta), f(gamma), f(alpha), [n], orc.fr_from_ints([1])) == 2
 
 
 def test_oracle_extended_quotient_satisfies_its_identity(orc):
