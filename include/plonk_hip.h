@@ -222,6 +222,23 @@ int32_t plk_kzg_cancel(plk_ctx* ctx);
 /* Like *_end but returns this shard's unnormalised partial (16 limbs) instead of the affine point. */
 int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]);
 
+/* ---- scheduling hint with no counterpart in the reference (which runs everything in sequence).  The library runs NTT, pointwise and
+ * scan kernels ("compute" work) on the same stream as the sorting stage of its MSMs, so that a commitment sees the polynomial the
+ * call before it produced.  Between plk_compute_detach(ctx, 1) and plk_compute_detach(ctx, 0) compute work goes to a second stream
+ * and runs beside the sorts and accumulations of the *_begin calls made in the same span: the selector transforms of
+ * src/prover.rs:232-233 beside the first commitment's sort, build_quotient_polynomial (src/prover.rs:248) beside z's.  Detaching orders
+ * the detached work after everything enqueued before; re-attaching orders everything after it.  In between the caller guarantees
+ * that no *_begin call reads what a detached compute call writes.  on = 2 re-attaches WITHOUT ordering later calls after the
+ * detached work (it keeps running beside them; only detached work enqueued later, or work after a later plk_compute_detach(ctx, 0),
+ * may read its results).  Results never depend on this call, only timing does. */
+int32_t plk_compute_detach(plk_ctx* ctx, int32_t on);
+/* plk_quotient_dev in two halves, so that the host can enqueue other work while the quotient's kernels run:
+ * _enqueue launches them (on the compute stream, detached or not) and returns; _finish waits and reports as plk_quotient_dev does. */
+int32_t plk_quotient_dev_enqueue(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals,
+                                 const void* q_mul_vals, const void* z_vals, const void* sigma, uint32_t log_n,
+                                 const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev);
+int32_t plk_quotient_dev_finish(plk_ctx* ctx, uint64_t* t_len);
+
 /* ---- element-wise field helpers used by tests and the microbenchmarks (op: 0 add, 1 sub, 2 mul; field: 0 Fr, 1 Fq) */
 int32_t plk_field_op(plk_ctx* ctx, int32_t field, int32_t op, const uint64_t* a_host, const uint64_t* b_host, uint64_t* out_host, uint64_t n);
 

@@ -82,6 +82,7 @@ static int32_t grow(plk_ctx* ctx, hipStream_t st, uint32_t** buf, uint64_t* cap,
 
 // orders the sort stream (the entry of the MSM pipeline) after everything already enqueued on the compute stream
 static int32_t sort_after_compute(plk_ctx* ctx) {
+    if (ctx->detached) return PLK_OK;   // the caller promised that this job's inputs do not come from the detached compute work
     hipEvent_t ev;
     PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     PLK_HIP(hipEventRecord(ev, ctx->stream));
@@ -183,6 +184,7 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
+    if (ctx->detached) { ctx->stream = ctx->st_sort; ctx->detached = false; }
     prof_collect(ctx, true);
     if (ctx->prof_base) hipEventDestroy(ctx->prof_base);
     for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
@@ -226,6 +228,31 @@ extern "C" int32_t plk_copy_dev(plk_ctx* ctx, void* dev_dst, const void* dev_src
     PLK_HIP(hipSetDevice(ctx->device));
     if (bytes) PLK_HIP(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (total_bytes > bytes) PLK_HIP(hipMemsetAsync((char*)dev_dst + bytes, 0, total_bytes - bytes, ctx->stream));
+    return PLK_OK;
+}
+// One stream after another: everything enqueued on `first` so far is ordered before whatever is enqueued on `then` from now on.
+static int32_t order_streams(plk_ctx* ctx, hipStream_t first, hipStream_t then) {
+    hipEvent_t ev;
+    PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PLK_HIP(hipEventRecord(ev, first));
+    PLK_HIP(hipStreamWaitEvent(then, ev, 0));
+    PLK_HIP(hipEventDestroy(ev));
+    return PLK_OK;
+}
+extern "C" int32_t plk_compute_detach(plk_ctx* ctx, int32_t on) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (on < 0 || on > 2) return PLK_ERR_INVALID_ARG;
+    if ((on == 1) == ctx->detached) return PLK_OK;
+    if (on == 1) {
+        PLK_TRY(order_streams(ctx, ctx->st_sort, ctx->st_red));   // detached work may read what earlier calls produced
+        ctx->stream = ctx->st_red;
+        ctx->detached = true;
+    } else {
+        if (on == 0) PLK_TRY(order_streams(ctx, ctx->st_red, ctx->st_sort));   // later calls may read what the detached work produced
+        ctx->stream = ctx->st_sort;
+        ctx->detached = false;
+    }
     return PLK_OK;
 }
 extern "C" int32_t plk_sync(plk_ctx* ctx) {
@@ -315,6 +342,8 @@ extern "C" int32_t plk_kzg_cancel(plk_ctx* ctx) {
     PLK_HIP(hipStreamSynchronize(ctx->st_red));
     ctx->reduce_pending.clear();
     for (auto& s : ctx->slot) s.busy = false;
+    if (ctx->detached) { ctx->stream = ctx->st_sort; ctx->detached = false; }   // everything was waited for above
+    ctx->quotient_stream = nullptr;
     return PLK_OK;
 }
 static int32_t ticket_slot(plk_ctx* ctx, int32_t ticket, int kind, MsmSlot** out) {

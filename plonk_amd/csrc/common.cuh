@@ -89,7 +89,8 @@ struct plk_ctx {
     // reduction + read-back on st_red: the accumulation kernels (most of a proof) run back to back while the
     // latency-bound stages of their neighbours fill in beside them.
     hipStream_t st_sort = nullptr, st_acc[2] = {nullptr, nullptr}, st_red = nullptr;
-    unsigned acc_turn = 0;
+    bool detached = false;             // plk_compute_detach: `stream` is st_red for the time being, so compute work runs beside the sorts on st_sort
+    uint64_t acc_load[2] = {0, 0};     // entries queued on each accumulation stream since the device was last idle
     plk::MsmSlot slot[plk::MSM_SLOTS];
     int next_slot = 0;
     std::vector<int> reduce_pending;   // slots whose sort and accumulation are enqueued but whose reduction is not yet (see msm_flush_reductions)
@@ -102,11 +103,12 @@ struct plk_ctx {
     // NTT
     std::map<int, uint32_t*> twiddles; // log_n -> w^i for i < n/2, x*2^261 form
     std::map<std::vector<uint64_t>, uint32_t*> coset_factors;   // per-element factor tables of the large transforms (x*2^261 form): (log_n, inverse, generator) -> g^i or n^-1 g^-i; (~0, log_n, inverse, pass, ...) -> inter-pass twiddles
-    uint32_t* ntt_tmp[2] = {nullptr, nullptr};
-    uint64_t ntt_tmp_cap = 0;
+    uint32_t* ntt_tmp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // ping-pong buffers of multi-pass transforms: set 0 for the attached compute stream, set 1 for detached work (the two may run at once)
+    uint64_t ntt_tmp_cap[2] = {0, 0};
     // scratch for pointwise / scan kernels
     uint32_t* scratch = nullptr;
     uint64_t scratch_cap = 0;
+    hipStream_t quotient_stream = nullptr;   // stream of a quotient enqueued with plk_quotient_dev_enqueue and not yet finished
     uint32_t* flag_dev = nullptr;
     uint32_t* flag_host = nullptr;
     // profiling

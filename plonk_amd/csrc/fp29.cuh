@@ -78,6 +78,25 @@ PLK_HD void pack(const fe& a, uint32_t* w) {
     }
 }
 
+// acc + a * b as one v_mad_u64_u32.  Written as inline assembly on the device so that every column of a product stays ONE chain of
+// multiply-adds that starts from the carry of the column before: left to itself the compiler starts each column from zero (to have
+// independent chains) and then pays a 64-bit addition per column to bring the carry in.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PLK_ASM_MAD)
+__device__ __forceinline__ uint64_t mad_vv(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) {   // b: a constant (modulus limb), kept in a scalar register
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+#else
+PLK_HD uint64_t mad_vv(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+PLK_HD uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+#endif
+
 // a * b * 2^-261 mod p (see the header comment for operand requirements); result normalized, bound 2
 template <class F>
 PLK_HD fe mul(const fe& a, const fe& b) {
@@ -87,19 +106,19 @@ PLK_HD fe mul(const fe& a, const fe& b) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        for (int i = 0; i <= k; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        for (int i = 0; i < k; ++i) acc = mad_vs(m[i], F::P[k - i], acc);
         m[k] = ((uint32_t)acc * F::NINV) & M29;
-        acc += (uint64_t)m[k] * F::P[0];
+        acc = mad_vs(m[k], F::P[0], acc);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        for (int i = k - 8; i < 9; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        for (int i = k - 8; i < 9; ++i) acc = mad_vs(m[i], F::P[k - i], acc);
         r.v[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
@@ -118,23 +137,23 @@ PLK_HD fe mul2(const fe& a, const fe& b, const fe& c, const fe& d) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        for (int i = 0; i <= k; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+        for (int i = 0; i <= k; ++i) acc = mad_vv(c.v[i], d.v[k - i], acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        for (int i = 0; i < k; ++i) acc = mad_vs(m[i], F::P[k - i], acc);
         m[k] = ((uint32_t)acc * F::NINV) & M29;
-        acc += (uint64_t)m[k] * F::P[0];
+        acc = mad_vs(m[k], F::P[0], acc);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        for (int i = k - 8; i < 9; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+        for (int i = k - 8; i < 9; ++i) acc = mad_vv(c.v[i], d.v[k - i], acc);
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        for (int i = k - 8; i < 9; ++i) acc = mad_vs(m[i], F::P[k - i], acc);
         r.v[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }
@@ -153,21 +172,21 @@ PLK_HD fe sqr(const fe& a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.v[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        for (int i = 0; 2 * i < k; ++i) acc = mad_vv(d[i], a.v[k - i], acc);
+        if ((k & 1) == 0) acc = mad_vv(a.v[k / 2], a.v[k / 2], acc);
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        for (int i = 0; i < k; ++i) acc = mad_vs(m[i], F::P[k - i], acc);
         m[k] = ((uint32_t)acc * F::NINV) & M29;
-        acc += (uint64_t)m[k] * F::P[0];
+        acc = mad_vs(m[k], F::P[0], acc);
         acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; ++k) {
 #pragma unroll
-        for (int i = k - 8; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.v[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        for (int i = k - 8; 2 * i < k; ++i) acc = mad_vv(d[i], a.v[k - i], acc);
+        if ((k & 1) == 0) acc = mad_vv(a.v[k / 2], a.v[k / 2], acc);
 #pragma unroll
-        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * F::P[k - i];
+        for (int i = k - 8; i < 9; ++i) acc = mad_vs(m[i], F::P[k - i], acc);
         r.v[k - 9] = (uint32_t)acc & M29;
         acc >>= 29;
     }

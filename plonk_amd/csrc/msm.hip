@@ -282,8 +282,19 @@ struct ReduceBatch {
 // bucket_sums[b] = flushed[b] (if the bucket ended inside a run) + the tails of all lanes whose run ended inside bucket b.
 // FOLD_LANES lanes per bucket share the tails, a shuffle tree joins them.
 template <int FOLD_LANES>
+__device__ __forceinline__ void fold_body(const ReduceBatch& rb);
+// Two builds of every reduction kernel.  "side": held to 128 registers so that its waves fit beside two accumulation waves per SIMD
+// (they spill, which costs nothing that matters: these reductions run beside the accumulation kernels of later MSMs).
+// "tail": no register limit, for the reduction that ends a batch: nothing else is running then, and the round waits for it.
+template <int FOLD_LANES>
 __global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(ReduceBatch rb) {
     PLK_SIDE_PRIO();
+    fold_body<FOLD_LANES>(rb);
+}
+template <int FOLD_LANES>
+__global__ void __launch_bounds__(256) k_msm_fold_tail(ReduceBatch rb) { fold_body<FOLD_LANES>(rb); }
+template <int FOLD_LANES>
+__device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
     const uint32_t* __restrict__ bucket_start = rb.bucket_start[blockIdx.y];
     const uint32_t* __restrict__ tails = rb.tails[blockIdx.y];
     const uint32_t* __restrict__ flushed = rb.flushed[blockIdx.y];
@@ -315,8 +326,19 @@ constexpr int MARG_K = 8;
 constexpr int MARG_PART_A = (MSM_BUCKETS >> 4) / MARG_K, MARG_PART_B = (MSM_BUCKETS >> 3) / MARG_K;   // partial sums per output: 256, 512
 constexpr int MARG_PARTIALS = 48 * MARG_PART_A + 8 * MARG_PART_B;                                     // 16384 per MSM
 __device__ __forceinline__ void marginal_of(uint32_t o, uint32_t* d, uint32_t* v) { *d = o < 48 ? o >> 4 : 3; *v = o < 48 ? (o & 15) : o - 48; }
+__device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb);
+__device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb);
 __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(ReduceBatch rb) {
     PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
+    marginals_part_body(rb);
+}
+__global__ void __launch_bounds__(64) k_msm_marginals_part_tail(ReduceBatch rb) { marginals_part_body(rb); }
+__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(ReduceBatch rb) {
+    PLK_SIDE_PRIO();
+    marginals_join_body(rb);
+}
+__global__ void __launch_bounds__(64) k_msm_marginals_join_tail(ReduceBatch rb) { marginals_join_body(rb); }
+__device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb) {
     const uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
     uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
     const uint32_t lane_id = blockIdx.x * 64 + threadIdx.x;     // < MARG_PARTIALS
@@ -335,8 +357,7 @@ __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(Red
     }
     st_xyzz(part + (size_t)lane_id * XYZZ_WORDS, acc);
 }
-__global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(ReduceBatch rb) {
-    PLK_SIDE_PRIO();
+__device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb) {
     const uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
     uint32_t* __restrict__ out = rb.marg_dev[blockIdx.y];
     const uint32_t o = blockIdx.x, lane = threadIdx.x;
@@ -559,7 +580,14 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
                        log_split);
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.sorted, st));
-    st = ctx->st_acc[ctx->acc_turn++ & 1];
+    // The accumulation goes to the stream with less work queued (entries of the jobs enqueued since the device was last idle): the kernel
+    // behind a long one would otherwise wait for it to drain completely while the other stream has nothing left to run.
+    bool idle = ctx->reduce_pending.empty();
+    for (const auto& other : ctx->slot) idle = idle && (!other.busy || &other == &s);
+    if (idle) ctx->acc_load[0] = ctx->acc_load[1] = 0;
+    const int acc_stream = ctx->acc_load[1] < ctx->acc_load[0] ? 1 : 0;
+    ctx->acc_load[acc_stream] += max_entries + 65536;   // a launch costs something even when it is empty
+    st = ctx->st_acc[acc_stream];
     PLK_HIP(hipStreamWaitEvent(st, s.sorted, 0));
     const uint32_t acc_blocks = (uint32_t)((acc_lanes(max_entries, acc_run(max_entries)) + ACC_THREADS - 1) / ACC_THREADS);
     prof_begin(ctx, st, "msm_accumulate");
@@ -567,7 +595,7 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.accumulated, st));
     s.max_entries = max_entries;
-    s.acc_stream = (int)((ctx->acc_turn - 1) & 1);
+    s.acc_stream = acc_stream;
     s.acc_blocks = acc_blocks;
     ctx->reduce_pending.push_back((int)(&s - ctx->slot));
     PLK_HIP(hipGetLastError());
@@ -578,7 +606,7 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
 // whose accumulation finished long ago.  Reductions are therefore not enqueued with their MSM but when the first result of a
 // batch is asked for, in the order in which the accumulations are expected to finish (two streams, taken alternately, each
 // kernel's time proportional to its entries).
-static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group) {
+static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group, bool tail) {
     hipStream_t st = ctx->st_red;
     ReduceBatch rb;
     memset(&rb, 0, sizeof(rb));
@@ -594,11 +622,20 @@ static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group) {
     }
     prof_begin(ctx, st, "msm_reduce");
     // runs that end inside an average bucket; two lanes per bucket keep the fold cheap, more lanes keep its serial chain short
-    if (tails_per_bucket <= 12) hipLaunchKernelGGL(k_msm_fold<2>, dim3(MSM_BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
-    else if (tails_per_bucket <= 48) hipLaunchKernelGGL(k_msm_fold<4>, dim3(MSM_BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
-    else hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
-    hipLaunchKernelGGL(k_msm_marginals_part, dim3(MARG_PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
-    hipLaunchKernelGGL(k_msm_marginals_join, dim3(MSM_MARGINALS, rb.n), dim3(64), 0, st, rb);
+    if (tail) {
+        // the batch ends with this reduction: all registers, no spills
+        if (tails_per_bucket <= 12) hipLaunchKernelGGL(k_msm_fold_tail<2>, dim3(MSM_BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
+        else if (tails_per_bucket <= 48) hipLaunchKernelGGL(k_msm_fold_tail<4>, dim3(MSM_BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
+        else hipLaunchKernelGGL(k_msm_fold_tail<8>, dim3(MSM_BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_part_tail, dim3(MARG_PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_join_tail, dim3(MSM_MARGINALS, rb.n), dim3(64), 0, st, rb);
+    } else {
+        if (tails_per_bucket <= 12) hipLaunchKernelGGL(k_msm_fold<2>, dim3(MSM_BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
+        else if (tails_per_bucket <= 48) hipLaunchKernelGGL(k_msm_fold<4>, dim3(MSM_BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
+        else hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_part, dim3(MARG_PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_join, dim3(MSM_MARGINALS, rb.n), dim3(64), 0, st, rb);
+    }
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
     for (int i = 0; i < rb.n; ++i) {
@@ -626,13 +663,13 @@ int32_t msm_flush_reductions(plk_ctx* ctx) {
     for (const auto& o : order) {
         const uint64_t e = ctx->slot[o.second].max_entries;
         if (!group.empty() && group_entries + e > GROUP_ENTRIES) {
-            PLK_TRY(enqueue_reduction(ctx, group));
+            PLK_TRY(enqueue_reduction(ctx, group, false));
             group.clear(); group_entries = 0;
         }
         group.push_back(o.second);
         group_entries += e;
     }
-    if (!group.empty()) PLK_TRY(enqueue_reduction(ctx, group));
+    if (!group.empty()) PLK_TRY(enqueue_reduction(ctx, group, true));   // the last group to finish ends the batch
     return PLK_OK;
 }
 

@@ -433,8 +433,10 @@ void ntt_release(plk_ctx* ctx) {
     ctx->twiddles.clear();
     for (auto& kv : ctx->coset_factors) hipFree(kv.second);
     ctx->coset_factors.clear();
-    hipFree(ctx->ntt_tmp[0]); hipFree(ctx->ntt_tmp[1]);
-    ctx->ntt_tmp[0] = ctx->ntt_tmp[1] = nullptr; ctx->ntt_tmp_cap = 0;
+    for (int k = 0; k < 2; ++k) {
+        hipFree(ctx->ntt_tmp[k][0]); hipFree(ctx->ntt_tmp[k][1]);
+        ctx->ntt_tmp[k][0] = ctx->ntt_tmp[k][1] = nullptr; ctx->ntt_tmp_cap[k] = 0;
+    }
 }
 
 static int32_t scale_powers(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint64_t n, const host::el& g, const host::el& base) {
@@ -472,6 +474,7 @@ static int32_t coset_factors(plk_ctx* ctx, hipStream_t st, uint32_t log_n, bool 
     if (hipMalloc(&table, n * 32) != hipSuccess) { ctx->err = "out of device memory for the coset factors"; return PLK_ERR_ALLOC; }
     hipLaunchKernelGGL(k_power_table, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, table, n, power_args(g, base));
     PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(st));   // built once, then read by transforms on either compute stream
     ctx->coset_factors[key] = table;
     *out = table;
     return PLK_OK;
@@ -490,6 +493,7 @@ static int32_t pass_twiddles(plk_ctx* ctx, hipStream_t st, const uint32_t* W, ui
     if (hipMalloc(&table, n * 32) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return PLK_OK; }   // no room: the pass gathers instead
     hipLaunchKernelGGL(k_pass_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, W, log_n, next_log_r, lns2, inverse ? 1 : 0);
     PLK_HIP(hipGetLastError());
+    PLK_HIP(hipStreamSynchronize(st));   // built once, then read by transforms on either compute stream
     ctx->coset_factors[key] = table;
     *out = table;
     return PLK_OK;
@@ -517,13 +521,15 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
             acc += lr[p];
         }
     }
-    if (npass > 1 && ctx->ntt_tmp_cap < n) {
+    const int set = st == ctx->st_red ? 1 : 0;   // detached transforms have buffers of their own
+    uint32_t** tmp = ctx->ntt_tmp[set];
+    if (npass > 1 && ctx->ntt_tmp_cap[set] < n) {
         PLK_HIP(hipStreamSynchronize(st));
-        hipFree(ctx->ntt_tmp[0]); hipFree(ctx->ntt_tmp[1]);
-        ctx->ntt_tmp[0] = ctx->ntt_tmp[1] = nullptr; ctx->ntt_tmp_cap = 0;
-        PLK_HIP(hipMalloc(&ctx->ntt_tmp[0], n * 32));
-        PLK_HIP(hipMalloc(&ctx->ntt_tmp[1], n * 32));
-        ctx->ntt_tmp_cap = n;
+        hipFree(tmp[0]); hipFree(tmp[1]);
+        tmp[0] = tmp[1] = nullptr; ctx->ntt_tmp_cap[set] = 0;
+        PLK_HIP(hipMalloc(&tmp[0], n * 32));
+        PLK_HIP(hipMalloc(&tmp[1], n * 32));
+        ctx->ntt_tmp_cap[set] = n;
     }
     const uint32_t* factors = nullptr;
     if (coset_gen && big) PLK_TRY(coset_factors(ctx, st, log_n, inverse, coset_gen, &factors));
@@ -538,7 +544,7 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
     const uint32_t* src = data;
     for (uint32_t p = 0; p < npass; ++p) {
         const bool last = p + 1 == npass;
-        uint32_t* dst = last ? data : ctx->ntt_tmp[p & 1];
+        uint32_t* dst = last ? data : tmp[p & 1];
         if (!big) {
             hipLaunchKernelGGL(k_ntt_pass, dim3(1), dim3(NTT_THREADS), 0, st, src, dst, W, log_n, lr[p], lns[p], lt[p], inverse ? 1 : 0, last ? 1 : 0,
                                (last && inverse) ? 1 : 0, ninv);

@@ -649,11 +649,12 @@ extern "C" int32_t plk_grand_product(plk_ctx* ctx, const uint64_t* witness_flat_
     return PLK_OK;
 }
 
-extern "C" int32_t plk_quotient_pi_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
-                                       const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
-                                       const uint64_t alpha[4], const uint64_t* pi_rows_host, const uint64_t* pi_values_host, uint64_t pi_count,
-                                       void* t_out_dev, uint64_t* t_len) {
-    if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !beta || !gamma || !t_out_dev || !t_len || log_n > 26)
+// t_len == nullptr: enqueue only (the verdict is collected by plk_quotient_dev_finish)
+static int32_t quotient_enqueue(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                                const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                                const uint64_t alpha[4], const uint64_t* pi_rows_host, const uint64_t* pi_values_host, uint64_t pi_count,
+                                void* t_out_dev, uint64_t* t_len) {
+    if (!ctx || !a || !b || !c || !q_add_vals || !q_mul_vals || !z_vals || !sigma || !beta || !gamma || !t_out_dev || log_n > 26)
         return PLK_ERR_INVALID_ARG;
     if (pi_count && (!alpha || !pi_rows_host || !pi_values_host)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
@@ -692,14 +693,40 @@ extern "C" int32_t plk_quotient_pi_dev(plk_ctx* ctx, const void* a, const void* 
     PLK_TRY(ntt_run(ctx, st, t, log_n, true, nullptr));
     // divide_by_vanishing_poly on a numerator of degree < n: quotient 0, remainder = the numerator, which must vanish
     hipLaunchKernelGGL(k_any_nonzero, dim3(256), dim3(256), 0, st, t, n * 8, ctx->flag_dev);
-    uint32_t flag;
-    PLK_TRY(read_flag(ctx, &flag));
+    PLK_HIP(hipGetLastError());
+    PLK_HIP(hipMemcpyAsync(ctx->flag_host, ctx->flag_dev, 4, hipMemcpyDeviceToHost, st));
+    ctx->quotient_stream = st;
+    if (!t_len) return PLK_OK;     // split form: plk_quotient_dev_finish collects the verdict (no public inputs there, so nothing to keep alive)
+    return plk_quotient_dev_finish(ctx, t_len);
+}
+extern "C" int32_t plk_quotient_dev_enqueue(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                                            const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                                            void* t_out_dev) {
+    if (ctx && ctx->quotient_stream) { ctx->err = "plk_quotient_dev_enqueue: the previous quotient was not finished"; return PLK_ERR_INVALID_ARG; }
+    return quotient_enqueue(ctx, a, b, c, q_add_vals, q_mul_vals, z_vals, sigma, log_n, beta, gamma, nullptr, nullptr, nullptr, 0, t_out_dev, nullptr);
+}
+extern "C" int32_t plk_quotient_dev_finish(plk_ctx* ctx, uint64_t* t_len) {
+    if (!ctx || !t_len) return PLK_ERR_INVALID_ARG;
+    if (!ctx->quotient_stream) { ctx->err = "plk_quotient_dev_finish: no quotient enqueued"; return PLK_ERR_INVALID_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->quotient_stream;
+    ctx->quotient_stream = nullptr;
+    PLK_HIP(hipStreamSynchronize(st));
+    const uint32_t flag = *ctx->flag_host;
     prof_collect(ctx, false);
     if (flag & 2u) { ctx->err = "sigma entry out of range"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
     if (flag & 4u) { ctx->err = "permutation constraint: inverse of zero"; return PLK_ERR_INVERSE_OF_ZERO; }
     if (flag & 1u) { ctx->err = "t(X) not divisible by Z_H(X)"; return PLK_ERR_NOT_DIVISIBLE; }
     *t_len = 0;
     return PLK_OK;
+}
+extern "C" int32_t plk_quotient_pi_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
+                                       const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                                       const uint64_t alpha[4], const uint64_t* pi_rows_host, const uint64_t* pi_values_host, uint64_t pi_count,
+                                       void* t_out_dev, uint64_t* t_len) {
+    if (!t_len) return PLK_ERR_INVALID_ARG;
+    if (ctx && ctx->quotient_stream) { ctx->err = "a quotient enqueued with plk_quotient_dev_enqueue is still open"; return PLK_ERR_INVALID_ARG; }
+    return quotient_enqueue(ctx, a, b, c, q_add_vals, q_mul_vals, z_vals, sigma, log_n, beta, gamma, alpha, pi_rows_host, pi_values_host, pi_count, t_out_dev, t_len);
 }
 extern "C" int32_t plk_quotient_dev(plk_ctx* ctx, const void* a, const void* b, const void* c, const void* q_add_vals, const void* q_mul_vals,
                                     const void* z_vals, const void* sigma, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4], void* t_out_dev,

@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PLK_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libplonk_hip.so")   # the override serves kernel experiments (tools/)
+# PLK_LIB_DIR (a directory holding both libraries) and PLK_LIB_OVERRIDE (this library alone) serve kernel experiments (tools/ab.sh)
+LIB_DIR = os.environ.get("PLK_LIB_DIR") or os.path.join(_HERE, "lib")
+LIB_PATH = os.environ.get("PLK_LIB_OVERRIDE") or os.path.join(LIB_DIR, "libplonk_hip.so")
 
 STATUS = {
     0: "PLK_OK", 1: "PLK_ERR_INVALID_ARG", 2: "PLK_ERR_HIP", 3: "PLK_ERR_NO_DEVICE", 4: "PLK_ERR_SRS_TOO_SHORT",
@@ -24,9 +26,9 @@ EXPORTS = [
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
-    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
+    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_dev_enqueue", "plk_quotient_dev_finish", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
-    "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
+    "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_compute_detach", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
 ]
 
@@ -57,8 +59,9 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C plonk_amd/csrc` (no CPU fallback exists)")
         _lib = C.CDLL(LIB_PATH)
-        for name in EXPORTS:
-            getattr(_lib, name)
+        if not os.environ.get("PLK_LIB_DIR"):      # an experiment directory may hold an older build
+            for name in EXPORTS:
+                getattr(_lib, name)
         _lib.plk_last_error.restype = C.c_char_p
         _lib.plk_last_error.argtypes = [C.c_void_p]
     return _lib
@@ -127,6 +130,19 @@ class Context:
         if out.nbytes:
             self._ck(self.lib.plk_download(self.h, _ptr(out), _vp(dptr), C.c_uint64(out.nbytes)))
         return out
+
+    def compute_detach(self, on):
+        """0 re-attach and order, 1 detach, 2 re-attach without ordering (include/plonk_hip.h)"""
+        self._ck(self.lib.plk_compute_detach(self.h, C.c_int32(int(on))))
+
+    def quotient_dev_enqueue(self, d_a, d_b, d_c, d_qa, d_qm, d_zv, d_sigma, log_n, beta, gamma, d_t):
+        self._ck(self.lib.plk_quotient_dev_enqueue(self.h, _vp(d_a), _vp(d_b), _vp(d_c), _vp(d_qa), _vp(d_qm), _vp(d_zv), _vp(d_sigma), C.c_uint32(log_n),
+                                                   _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))), _vp(d_t)))
+
+    def quotient_dev_finish(self):
+        tlen = C.c_uint64(0)
+        self._ck(self.lib.plk_quotient_dev_finish(self.h, C.byref(tlen)))
+        return tlen.value
 
     def sync(self):
         self._ck(self.lib.plk_sync(self.h))

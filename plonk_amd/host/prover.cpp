@@ -197,14 +197,6 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
             check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
         }
         check(ctx, plk_kzg_submit(ctx));
-        // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233) depend on no challenge: they are enqueued here,
-        // behind the sorts, and run beside the accumulation kernels instead of on the critical path between rounds 2 and 4.
-        if (in.len[0] >= n && in.len[1] >= n && in.len[2] >= n) {
-            check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
-            check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
-            check(ctx, plk_ntt_dev_enqueue(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
-            check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
-        }
         G1Affine c7[7];
         finish_points(pk, ticket, 7, false, c7, nullptr, nullptr, order);
         for (int i = 0; i < 7; ++i) comm[i].comm = c7[i];
@@ -224,9 +216,29 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     // transforms and pointwise pass (which need z but not its commitment) use the compute stream.
     // z_vals = domain.fft(&z_poly.coeffs) (:237) are the values the interpolation started from: kept in work[3], no transform.
     void* z_coeffs = in.work[2];
+    // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233): on the detached compute stream, beside the grand
+    // product, whose kernels leave most of the chip idle.  Enqueued behind the sorts of round 1 their workgroups (72 KB of LDS, 157
+    // registers, four waves that must start together) found no room beside the single-wave workgroups of the accumulation kernels
+    // until the round's last kernel drained, and then ran on the critical path.
+    if (in.len[0] >= n && in.len[1] >= n && in.len[2] >= n) {
+        check(ctx, plk_compute_detach(ctx, 1));
+        check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
+        check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
+        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
+        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
+        check(ctx, plk_compute_detach(ctx, 2));   // the quotient, their only reader, is enqueued behind them on the detached stream
+    }
     check(ctx, plk_grand_product_values_dev(ctx, in.witness_flat, in.sigma, log_n, beta.v, gamma.v, in.work[3], z_coeffs));
     for (auto& r : blind[7]) r = rng();
     int32_t z_ticket;
+    // From here to the end of round 3 compute work is detached: the quotient's kernels then run beside the sort of z instead of
+    // queueing behind it, where they would meet z's accumulation kernel and be starved until it drains.  (z's coefficients were
+    // written on the attached stream, so the commitment below still sees them.)
+    check(ctx, plk_compute_detach(ctx, 1));
+    if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
+        throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
+    // round 3's kernels first (:224-259): the host then enqueues the sorts of z and t while they run
+    check(ctx, plk_quotient_dev_enqueue(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4]));
     check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
     // The quotient of this constraint system has degree < n before the division by Z_H, so it is either the zero polynomial or
     // the prover fails (:487).  Its commitment (three blinding terms, drawn here in the reference's rng order) is therefore
@@ -234,16 +246,16 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     for (auto& r : blind[8]) r = rng();
     int32_t t_ticket = -1;
     check(ctx, plk_kzg_commit_begin(ctx, in.work[4], 0, &blind[8][0].v[0], &t_ticket));
-    check(ctx, plk_kzg_submit(ctx));
     lap(1);
 
-    // ---- round 3: quotient t :224-259
+    // ---- round 3: quotient t :224-259, on the detached compute stream.  The reductions of z and t are enqueued (plk_kzg_submit)
+    // after it, because they share that stream and wait for z's accumulation.
     uint64_t t_len = 0;
     // a failure below leaves both tickets open: the caller of prove_rounds gives them up
-    if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
-        throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
-    check(ctx, plk_quotient_dev(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4],
-                                &t_len));
+    const int32_t rc_quotient = plk_quotient_dev_finish(ctx, &t_len);
+    check(ctx, plk_compute_detach(ctx, 0));
+    check(ctx, rc_quotient);
+    check(ctx, plk_kzg_submit(ctx));
     if (t_len != 0) {
         finish_point(pk, t_ticket);
         check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));

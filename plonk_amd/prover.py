@@ -18,7 +18,7 @@ import numpy as np
 from . import hip, synth
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_HERE, "lib", "libplonk_host.so")
+HOST_LIB_PATH = os.path.join(hip.LIB_DIR, "libplonk_host.so")
 HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate", "plonk_pk_generate_cyclic",
                 "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
                 "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip",
