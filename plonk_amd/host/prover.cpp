@@ -197,6 +197,20 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
             check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
         }
         check(ctx, plk_kzg_submit(ctx));
+        // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233) depend on no challenge.  They are enqueued here on the
+        // detached compute stream, which also carries the reductions just submitted: they start when the last reduction of the round
+        // has finished and run while the host finishes the commitments and the transcript, and beside the grand product, whose kernels
+        // leave most of the chip idle.  (Enqueued behind the sorts instead, their workgroups - 72 KB of LDS, 157 registers, four waves
+        // that must start together - found no room beside the single-wave workgroups of the accumulation kernels until the round's
+        // last kernel drained, and then ran on the critical path.)
+        if (in.len[0] >= n && in.len[1] >= n && in.len[2] >= n) {
+            check(ctx, plk_compute_detach(ctx, 1));
+            check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
+            check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
+            check(ctx, plk_ntt_dev_enqueue(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
+            check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
+            check(ctx, plk_compute_detach(ctx, 2));   // the quotient, their only reader, is enqueued behind them on the detached stream
+        }
         G1Affine c7[7];
         finish_points(pk, ticket, 7, false, c7, nullptr, nullptr, order);
         for (int i = 0; i < 7; ++i) comm[i].comm = c7[i];
@@ -216,18 +230,6 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     // transforms and pointwise pass (which need z but not its commitment) use the compute stream.
     // z_vals = domain.fft(&z_poly.coeffs) (:237) are the values the interpolation started from: kept in work[3], no transform.
     void* z_coeffs = in.work[2];
-    // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233): on the detached compute stream, beside the grand
-    // product, whose kernels leave most of the chip idle.  Enqueued behind the sorts of round 1 their workgroups (72 KB of LDS, 157
-    // registers, four waves that must start together) found no room beside the single-wave workgroups of the accumulation kernels
-    // until the round's last kernel drained, and then ran on the critical path.
-    if (in.len[0] >= n && in.len[1] >= n && in.len[2] >= n) {
-        check(ctx, plk_compute_detach(ctx, 1));
-        check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
-        check(ctx, plk_copy_dev(ctx, in.work[1], in.poly[4], in.len[4] * 32, n * 32));
-        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[0], log_n, 0, nullptr));            // q_add values :232
-        check(ctx, plk_ntt_dev_enqueue(ctx, in.work[1], log_n, 0, nullptr));            // q_mul values :233
-        check(ctx, plk_compute_detach(ctx, 2));   // the quotient, their only reader, is enqueued behind them on the detached stream
-    }
     check(ctx, plk_grand_product_values_dev(ctx, in.witness_flat, in.sigma, log_n, beta.v, gamma.v, in.work[3], z_coeffs));
     for (auto& r : blind[7]) r = rng();
     int32_t z_ticket;
@@ -237,7 +239,8 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     check(ctx, plk_compute_detach(ctx, 1));
     if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
         throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
-    // round 3's kernels first (:224-259): the host then enqueues the sorts of z and t while they run
+    // round 3's kernels first (:224-259): the host then enqueues the sorts of z and t while they run (measured: with the sort enqueued
+    // first the tail of the quotient's chain meets z's accumulation kernel and the round takes 0.1 ms longer)
     check(ctx, plk_quotient_dev_enqueue(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4]));
     check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
     // The quotient of this constraint system has degree < n before the division by Z_H, so it is either the zero polynomial or
