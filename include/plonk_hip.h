@@ -44,6 +44,15 @@ int32_t plk_malloc(plk_ctx* ctx, uint64_t bytes, void** dev);
 int32_t plk_free(plk_ctx* ctx, void* dev);
 int32_t plk_upload(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
 int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
+/* Upload without waiting, for a host that hands over its polynomials with the call (src/prover.rs:119-133 borrows host vectors): the
+ * transfer is enqueued on a stream of its own and every LATER call on this context that reads dev_dst is ordered after it, so the
+ * commitment of the first polynomial runs while the others are still crossing PCIe.  host_src must stay valid until a call that
+ * returns results of work reading dev_dst has returned (or plk_sync).  From pinned memory (plk_host_malloc) the call returns at
+ * once and the transfer runs at link speed; from ordinary memory it is correct but the runtime stages it and the call blocks. */
+int32_t plk_upload_enqueue(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
+/* page-locked host memory for plk_upload_enqueue */
+int32_t plk_host_malloc(plk_ctx* ctx, uint64_t bytes, void** host);
+int32_t plk_host_free(plk_ctx* ctx, void* host);
 int32_t plk_sync(plk_ctx* ctx);
 /* device-to-device copy of `bytes`, then zero fill up to `total_bytes` (zero padding of DensePolynomial coefficients) */
 int32_t plk_copy_dev(plk_ctx* ctx, void* dev_dst, const void* dev_src, uint64_t bytes, uint64_t total_bytes);

@@ -216,6 +216,33 @@ extern "C" int32_t plk_upload(plk_ctx* ctx, void* dev_dst, const void* host_src,
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     return PLK_OK;
 }
+// Upload that does not wait: the copy runs on the detached stream (st_red, idle at the start of a round), and the stream that carries
+// the compute work and the MSM sorts is ordered after it from this call on.  Later calls that read dev_dst therefore see the data,
+// earlier ones are not held up, and the transfers of several such calls follow each other without gaps.
+extern "C" int32_t plk_upload_enqueue(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dev_dst || !host_src))) return PLK_ERR_INVALID_ARG;
+    if (!bytes) return PLK_OK;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->st_red));
+    hipEvent_t ev;
+    PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PLK_HIP(hipEventRecord(ev, ctx->st_red));
+    PLK_HIP(hipStreamWaitEvent(ctx->st_sort, ev, 0));
+    PLK_HIP(hipEventDestroy(ev));
+    return PLK_OK;
+}
+extern "C" int32_t plk_host_malloc(plk_ctx* ctx, uint64_t bytes, void** host) {
+    if (!ctx || !host) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (hipHostMalloc(host, bytes ? bytes : 32, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->err = "pinned host allocation failed"; return PLK_ERR_ALLOC; }
+    return PLK_OK;
+}
+extern "C" int32_t plk_host_free(plk_ctx* ctx, void* host) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipHostFree(host));
+    return PLK_OK;
+}
 extern "C" int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes) {
     if (!ctx || (bytes && (!host_dst || !dev_src))) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));

@@ -21,7 +21,7 @@ STATUS = {
 }
 # every symbol include/plonk_hip.h declares
 EXPORTS = [
-    "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_download", "plk_sync", "plk_copy_dev",
+    "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_upload_enqueue", "plk_host_malloc", "plk_host_free", "plk_download", "plk_sync", "plk_copy_dev",
     "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_generate_cyclic", "plk_srs_load_cyclic", "plk_srs_setup", "plk_srs_setup_cyclic", "plk_srs_read",
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
@@ -124,6 +124,26 @@ class Context:
     def upload_into(self, dptr: int, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
         self._ck(self.lib.plk_upload(self.h, _vp(dptr), _ptr(arr), C.c_uint64(arr.nbytes)))
+
+    def upload_enqueue(self, dptr: int, arr: np.ndarray):
+        """plk_upload_enqueue: no wait; arr must stay alive (and unchanged) until results that depend on it have been returned"""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._ck(self.lib.plk_upload_enqueue(self.h, _vp(dptr), _ptr(arr), C.c_uint64(arr.nbytes)))
+
+    def host_empty(self, shape, dtype=np.uint64) -> np.ndarray:
+        """numpy array in page-locked host memory (plk_host_malloc); freed with host_free(arr)"""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._ck(self.lib.plk_host_malloc(self.h, C.c_uint64(nbytes), C.byref(p)))
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.__array_interface__["data"][0]] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = self._pinned.pop(arr.__array_interface__["data"][0])
+        self._ck(self.lib.plk_host_free(self.h, _vp(p)))
 
     def download(self, dptr: int, shape, dtype=np.uint64) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)

@@ -79,6 +79,37 @@ int32_t plonk_prove(void* pk, void* inputs, const uint64_t* public_inputs, uint6
     });
 }
 
+// plonk_prove on host arrays (the reference's call shape, src/prover.rs:119-133): polys as in plonk_inputs_create, borrowed, not copied.
+int32_t plonk_prove_host(void* pk, const uint64_t* const* polys, const uint64_t* lens, const uint64_t* witness_flat, const uint64_t* sigma, uint32_t log_n,
+                         const uint64_t* public_inputs, uint64_t n_public, const uint64_t* blinds, uint64_t n_blinds, uint8_t* proof_bytes, uint64_t* challenges,
+                         double* seconds) {
+    return guarded([&] {
+        HostInputs host;
+        for (int i = 0; i < 7; ++i) {
+            const Fr* p = reinterpret_cast<const Fr*>(polys[i]);
+            uint64_t len = lens[i];
+            while (len && p[len - 1].is_zero()) --len;   // from_coefficients_vec
+            host.poly[i] = p; host.len[i] = len;
+        }
+        host.witness_flat = reinterpret_cast<const Fr*>(witness_flat);
+        host.sigma = sigma;
+        host.domain = Domain{log_n};
+        std::vector<Fr> pub(n_public);
+        if (n_public) memcpy(pub.data(), public_inputs, n_public * 32);
+        uint64_t next = 0;
+        Rng rng = [&]() -> Fr {
+            if (next >= n_blinds) throw Error(PLK_ERR_INVALID_ARG, "rng exhausted: the prover draws 27 field elements");
+            Fr r; memcpy(r.v, blinds + 4 * next, 32); ++next; return r;
+        };
+        ProveTrace tr;
+        const PlonkProof proof = create_plonk_proof_with_transcript(*static_cast<KZGProverKey*>(pk), host, pub, rng, &tr);
+        const std::vector<uint8_t> bytes = serialize_proof(proof);
+        memcpy(proof_bytes, bytes.data(), bytes.size());
+        if (challenges) { memcpy(challenges, tr.beta.v, 32); memcpy(challenges + 4, tr.gamma.v, 32); memcpy(challenges + 8, tr.alpha.v, 32); memcpy(challenges + 12, tr.zeta.v, 32); }
+        if (seconds) memcpy(seconds, tr.seconds, sizeof(tr.seconds));
+    });
+}
+
 // src/verifier.rs:57 on serialized proof bytes, with the verifier key of the synthetic SRS (tau, gscal).  *ok = 1 when all nine openings check.
 int32_t plonk_verify(const uint64_t* tau, const uint64_t* gscal, const uint8_t* proof_bytes, uint64_t proof_len, const uint64_t* public_inputs, uint64_t n_public,
                      const uint64_t* opening_challenge, int32_t* ok) {

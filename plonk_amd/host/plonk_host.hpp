@@ -102,6 +102,7 @@ struct KZGVerifierKey;
 using AllGather = std::function<void(const uint64_t* mine, uint64_t count, uint64_t* all)>;
 
 // KZGProverKey (src/prover.rs:32): owns a plk_ctx with the powers resident in HBM.
+class DeviceInputs;
 class KZGProverKey {
 public:
     explicit KZGProverKey(int32_t device);
@@ -129,19 +130,35 @@ public:
     Fr opening_challenge{};
     uint32_t rank = 0, world_size = 1;
     AllGather gather;
+    // device buffers that proofs from host arrays stream their inputs into; kept between proofs, grown when a proof needs more
+    DeviceInputs& arena(const Domain& domain, const uint64_t len[7]) const;
 private:
     plk_ctx* ctx_ = nullptr;
     uint64_t len_ = 0;
+    mutable DeviceInputs* arena_ = nullptr;
 };
 
 // The prover's inputs resident in HBM (what create_plonk_proof_with_transcript borrows: seven polynomials,
 // witness_flat, sigma).  Built once, reused for any number of proofs.
+// The prover's arguments as the reference passes them: borrowed host memory (&DensePolynomial, &[Fr], &[usize], src/prover.rs:121-130).
+// len[i] counts coefficients after trailing zeros were stripped (DensePolynomial::from_coefficients_vec).
+struct HostInputs {
+    const Fr* poly[7];      // a, b, c, q_add, q_mul, s_id, s_sigma
+    uint64_t len[7];
+    const Fr* witness_flat; // 3n
+    const uint64_t* sigma;  // 3n
+    Domain domain;
+};
 class DeviceInputs {
 public:
     DeviceInputs(const KZGProverKey& pk, const DensePolynomial& a, const DensePolynomial& b, const DensePolynomial& c, const DensePolynomial& q_add,
                  const DensePolynomial& q_mul, const DensePolynomial& s_id, const DensePolynomial& s_sigma, const std::vector<Fr>& witness_flat,
                  const std::vector<uint64_t>& sigma, const Domain& domain);
+    // buffers only, for at most cap[i] coefficients each: filled by the prover itself from a HostInputs while it runs
+    DeviceInputs(const KZGProverKey& pk, const Domain& domain, const uint64_t cap[7]);
     ~DeviceInputs();
+    uint64_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    const HostInputs* host = nullptr;   // set while a proof streams its inputs in
     DeviceInputs(const DeviceInputs&) = delete;
     Domain domain;
     uint64_t len[7];
@@ -158,6 +175,9 @@ PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, const Dens
                                               const DensePolynomial& q_add, const DensePolynomial& q_mul, const DensePolynomial& s_id,
                                               const DensePolynomial& s_sigma, const std::vector<Fr>& public_inputs, const std::vector<Fr>& witness_flat,
                                               const std::vector<uint64_t>& sigma, const Domain& domain, Rng& rng, ProveTrace* trace = nullptr);
+// the same on borrowed host arrays (no copy on the host): the polynomials cross PCIe while the first commitments are computed
+PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, const HostInputs& host, const std::vector<Fr>& public_inputs, Rng& rng,
+                                              ProveTrace* trace = nullptr);
 // the same on inputs that already live in HBM
 PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, DeviceInputs& in, const std::vector<Fr>& public_inputs, Rng& rng,
                                               ProveTrace* trace = nullptr);

@@ -38,7 +38,22 @@ KZGProverKey::KZGProverKey(int32_t device) {
     const int32_t rc = plk_create(device, &ctx_);
     if (rc != PLK_OK) throw Error(rc, "plk_create failed: no usable GPU (there is no CPU fallback)");
 }
-KZGProverKey::~KZGProverKey() { if (ctx_) plk_destroy(ctx_); }
+KZGProverKey::~KZGProverKey() {
+    delete arena_;
+    if (ctx_) plk_destroy(ctx_);
+}
+DeviceInputs& KZGProverKey::arena(const Domain& domain, const uint64_t len[7]) const {
+    bool fits = arena_ && arena_->domain.log_size == domain.log_size;
+    for (int i = 0; i < 7 && fits; ++i) fits = len[i] <= arena_->cap[i];
+    if (!fits) {
+        uint64_t cap[7];
+        for (int i = 0; i < 7; ++i) cap[i] = std::max<uint64_t>(len[i], arena_ && arena_->domain.log_size == domain.log_size ? arena_->cap[i] : 0);
+        delete arena_;
+        arena_ = nullptr;
+        arena_ = new DeviceInputs(*this, domain, cap);
+    }
+    return *arena_;
+}
 void KZGProverKey::load(const uint64_t* g_xy, uint64_t len, const uint64_t* gamma_g_xy) {
     check(ctx_, plk_srs_load(ctx_, g_xy, len, gamma_g_xy));
     len_ = len;
@@ -81,6 +96,19 @@ DeviceInputs::DeviceInputs(const KZGProverKey& pk, const DensePolynomial& a, con
     check(ctx_, plk_upload(ctx_, witness_flat, wflat.data(), 3 * n * 32));
     check(ctx_, plk_malloc(ctx_, 3 * n * 8, &sigma));
     check(ctx_, plk_upload(ctx_, sigma, sg.data(), 3 * n * 8));
+    for (auto& w : work) check(ctx_, plk_malloc(ctx_, n * 32, &w));
+}
+DeviceInputs::DeviceInputs(const KZGProverKey& pk, const Domain& dom, const uint64_t caps[7]) : domain(dom), ctx_(pk.ctx()) {
+    const uint64_t n = dom.size();
+    for (int i = 0; i < 7; ++i) { poly[i] = nullptr; len[i] = 0; }
+    witness_flat = sigma = nullptr;
+    for (auto& w : work) w = nullptr;
+    for (int i = 0; i < 7; ++i) {
+        cap[i] = (i == 3 || i == 4) ? std::max<uint64_t>(caps[i], n) : std::max<uint64_t>(caps[i], 1);
+        check(ctx_, plk_malloc(ctx_, cap[i] * 32, &poly[i]));
+    }
+    check(ctx_, plk_malloc(ctx_, 3 * n * 32, &witness_flat));
+    check(ctx_, plk_malloc(ctx_, 3 * n * 8, &sigma));
     for (auto& w : work) check(ctx_, plk_malloc(ctx_, n * 32, &w));
 }
 DeviceInputs::~DeviceInputs() {
@@ -191,10 +219,27 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
             for (auto& r : blind[i]) r = rng();
         int order[7] = {0, 1, 2, 3, 4, 5, 6};
         msm_order(order, 7, in.len);
+        if (in.host) {
+            // Inputs still on the host: they cross PCIe in the order in which they are committed, shortest first, so that the first
+            // sort starts after one polynomial's transfer and the accumulation kernels of the short ones cover the transfer of the
+            // 4n-coefficient s_sigma (plk_upload_enqueue orders each sort behind its own polynomial only).
+            std::vector<int> tiny, rest;
+            for (int i = 0; i < 7; ++i) (in.len[i] <= 16 ? tiny : rest).push_back(i);
+            std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) { return in.len[x] < in.len[y]; });
+            int k = 0;   // an ordinary polynomial leads, the tiny ones follow it (msm_order's reasons)
+            if (!rest.empty()) order[k++] = rest[0];
+            for (int i : tiny) order[k++] = i;
+            for (size_t r = 1; r < rest.size(); ++r) order[k++] = rest[r];
+        }
         int32_t ticket[7];
         for (int k = 0; k < 7; ++k) {
             const int i = order[k];
+            if (in.host) check(ctx, plk_upload_enqueue(ctx, in.poly[i], in.host->poly[i], in.len[i] * 32));
             check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
+        }
+        if (in.host) {   // needed from round 2 on: behind the polynomials
+            check(ctx, plk_upload_enqueue(ctx, in.witness_flat, in.host->witness_flat, 3 * n * 32));
+            check(ctx, plk_upload_enqueue(ctx, in.sigma, in.host->sigma, 3 * n * 8));
         }
         check(ctx, plk_kzg_submit(ctx));
         // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233) depend on no challenge.  They are enqueued here on the
@@ -306,12 +351,31 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     return proof;
 }
 
+PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, const HostInputs& host, const std::vector<Fr>& public_inputs, Rng& rng, ProveTrace* trace) {
+    DeviceInputs& in = pk.arena(host.domain, host.len);
+    for (int i = 0; i < 7; ++i) in.len[i] = host.len[i];
+    in.host = &host;
+    struct Reset { DeviceInputs& d; ~Reset() { d.host = nullptr; } } reset{in};
+    return create_plonk_proof_with_transcript(pk, in, public_inputs, rng, trace);
+}
 PlonkProof create_plonk_proof_with_transcript(const KZGProverKey& pk, const DensePolynomial& a, const DensePolynomial& b, const DensePolynomial& c,
                                               const DensePolynomial& q_add, const DensePolynomial& q_mul, const DensePolynomial& s_id,
                                               const DensePolynomial& s_sigma, const std::vector<Fr>& public_inputs, const std::vector<Fr>& witness_flat,
                                               const std::vector<uint64_t>& sigma, const Domain& domain, Rng& rng, ProveTrace* trace) {
-    DeviceInputs in(pk, a, b, c, q_add, q_mul, s_id, s_sigma, witness_flat, sigma, domain);
-    return create_plonk_proof_with_transcript(pk, in, public_inputs, rng, trace);
+    const uint64_t n = domain.size();
+    if (witness_flat.size() != 3 * n || sigma.size() != 3 * n) throw Error(PLK_ERR_INVALID_ARG, "witness_flat and sigma must have 3 * domain.size() entries");
+    const DensePolynomial* polys[7] = {&a, &b, &c, &q_add, &q_mul, &s_id, &s_sigma};
+    HostInputs host;
+    for (int i = 0; i < 7; ++i) {
+        uint64_t len = polys[i]->coeffs.size();
+        while (len && polys[i]->coeffs[len - 1].is_zero()) --len;   // from_coefficients_vec
+        host.poly[i] = polys[i]->coeffs.data();
+        host.len[i] = len;
+    }
+    host.witness_flat = witness_flat.data();
+    host.sigma = sigma.data();
+    host.domain = domain;
+    return create_plonk_proof_with_transcript(pk, host, public_inputs, rng, trace);
 }
 
 DensePolynomial build_grand_product(const KZGProverKey& pk, const std::vector<Fr>& witness_flat, const std::vector<uint64_t>& sigma, const Domain& domain,

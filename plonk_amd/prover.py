@@ -20,7 +20,7 @@ from . import hip, synth
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(hip.LIB_DIR, "libplonk_host.so")
 HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate", "plonk_pk_generate_cyclic",
-                "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove",
+                "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove", "plonk_prove_host",
                 "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip",
                 "plonk_rng_create", "plonk_rng_destroy", "plonk_rng_next_u64", "plonk_rng_next_u32", "plonk_rng_fr", "plonk_rng_g1", "plonk_rng_g2",
                 "plonk_chacha_block", "plonk_test_sponge_challenge", "plonk_pk_setup", "plonk_prove_rng", "plonk_verify_vk", "plonk_circuit_tables"]
@@ -252,6 +252,22 @@ class ProverKey:
                                       _ptr(ch), _ptr(sec)))
         return ProofResult(proof.tobytes(), ch, sec)
 
+
+    def prove_host(self, polys, witness_flat, sigma, log_n, blinds, public_inputs=None) -> ProofResult:
+        """create_plonk_proof_with_transcript on host arrays (src/prover.rs:119-133 borrows host vectors): a, b, c, q_add, q_mul, s_id,
+        s_sigma as (len, 4) uint64 arrays, not copied; they cross PCIe while the first commitments run (at link speed from arrays made
+        with ctx.host_empty, staged by the runtime from ordinary ones)."""
+        ps = [p if (p.dtype == np.uint64 and p.flags["C_CONTIGUOUS"]) else _u64(p, (-1, 4)) for p in polys]
+        w = witness_flat if (witness_flat.dtype == np.uint64 and witness_flat.flags["C_CONTIGUOUS"]) else _u64(witness_flat)
+        sg = sigma if (sigma.dtype == np.uint64 and sigma.flags["C_CONTIGUOUS"]) else _u64(sigma)
+        ptrs = (C.c_void_p * 7)(*[p.ctypes.data if len(p) else None for p in ps])
+        lens = np.array([len(p) for p in ps], dtype=np.uint64)
+        bl = _u64(blinds, (-1, 4))
+        pub = _u64(public_inputs, (-1, 4)) if public_inputs is not None and len(public_inputs) else None
+        proof = np.zeros(1170, dtype=np.uint8); ch = np.zeros((4, 4), dtype=np.uint64); sec = np.zeros(6, dtype=np.float64)
+        self._ck(self.lib.plonk_prove_host(self.h, ptrs, _ptr(lens), _ptr(w), _ptr(sg), C.c_uint32(log_n), _ptr(pub), C.c_uint64(0 if pub is None else len(pub)),
+                                           _ptr(bl), C.c_uint64(len(bl)), _ptr(proof), _ptr(ch), _ptr(sec)))
+        return ProofResult(proof.tobytes(), ch, sec)
 
     def prove_rng(self, inputs: DeviceInputs, rng: StdRng, public_inputs=None) -> ProofResult:
         """prove() with the 27 blinding coefficients drawn from rng (the reference's `rng: &mut R`, src/prover.rs:132)."""

@@ -270,3 +270,33 @@ def test_cxx_replay_of_the_reference_driver(pk, orc):
     want = pk.prove_rng(inputs, rng).proof_bytes
     inputs.close()
     assert lines[0] == "proof " + want.hex()
+
+
+@pytest.mark.parametrize("log_n", [3, 10, 14])
+def test_proof_from_host_arrays_equals_the_resident_one(pk, orc, log_n):
+    """create_plonk_proof_with_transcript on borrowed host arrays (src/prover.rs:119-133): the polynomials are uploaded by the prover
+    itself while its first commitments run.  Same bytes as the proof of inputs that were resident beforehand, from ordinary and from
+    page-locked arrays, and again after a proof of another size has used the same device buffers."""
+    variables, gates = synth.synthetic_circuit(log_n, seed=40 + log_n)
+    tables = synth.circuit_tables(variables, gates)
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
+    pk.set_opening_challenge(synth.to_mont([0x1234567890ABCDEF1122334455667788])[0])
+    blinds = synth.seeded_scalars(27, 9)
+    inputs = pk.prepare(tables)
+    want = pk.prove(inputs, blinds)
+    polys = [np.ascontiguousarray(p) for p in inputs.polys]
+    wflat = np.ascontiguousarray(tables["witness_flat"], dtype=np.uint64); sigma = np.ascontiguousarray(tables["sigma"], dtype=np.uint64)
+    got = pk.prove_host(polys, wflat, sigma, tables["log_n"], blinds)
+    assert got.proof_bytes == want.proof_bytes and np.array_equal(got.challenges, want.challenges)
+    # trailing zeros are stripped as DensePolynomial::from_coefficients_vec does
+    padded = [np.concatenate([p, np.zeros((3, 4), np.uint64)]) for p in polys]
+    assert pk.prove_host(padded, wflat, sigma, tables["log_n"], blinds).proof_bytes == want.proof_bytes
+    pinned = []
+    for a in polys + [wflat, sigma]:
+        h = pk.ctx.host_empty(a.shape, a.dtype); h[...] = a; pinned.append(h)
+    got = pk.prove_host(pinned[:7], pinned[7], pinned[8], tables["log_n"], blinds)
+    assert got.proof_bytes == want.proof_bytes
+    for h in pinned:
+        pk.ctx.host_free(h)
+    inputs.close()
