@@ -10,9 +10,14 @@ fn main() {
     let csrc = root.join("plonk_amd").join("csrc");
     let status = Command::new("make").arg("-C").arg(&csrc).arg("-j8").status().expect("make not found");
     assert!(status.success(), "building libplonk_hip.so failed");
+    // the whole-proof entry point behind src/prover_fast.rs (include/plonk_host.h), plain g++
+    let status = Command::new("make").arg("-C").arg(root.join("plonk_amd").join("host")).status().expect("make not found");
+    assert!(status.success(), "building libplonk_host.so failed");
     let lib = root.join("plonk_amd").join("lib");
     println!("cargo:rustc-link-search=native={}", lib.display());
     println!("cargo:rustc-link-lib=dylib=plonk_hip");
+    println!("cargo:rustc-link-lib=dylib=plonk_host");
+    println!("cargo:rerun-if-changed={}", root.join("include").join("plonk_host.h").display());
     println!("cargo:rustc-link-arg=-Wl,-rpath,{}", lib.display());
     println!("cargo:rerun-if-changed={}", root.join("include").join("plonk_hip.h").display());
     println!("cargo:rerun-if-env-changed=PLONK_HIP_ROOT");

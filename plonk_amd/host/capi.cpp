@@ -2,6 +2,7 @@
 // the C++ surface of plonk_host.hpp; failures come back as a status code plus the reference-style message.
 #include "plonk_host.hpp"
 #include "circuit.hpp"
+#include "../../include/plonk_host.h"   // the public declarations of what is defined here: a mismatch does not compile
 #include <string.h>
 #include <string>
 

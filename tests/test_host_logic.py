@@ -117,6 +117,18 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/plonk_host.h (the whole-proof surface the Rust drop-in binds) against libplonk_host.so"""
+    from plonk_amd import prover
+    header = open(os.path.join(ROOT, "include", "plonk_host.h")).read()
+    declared = sorted(set(re.findall(r"\b(plonk_[a-z0-9_]+)\s*\(", header)) - {"plonk_gather_fn"})
+    assert len(declared) >= 20 and "plonk_prove_host" in declared
+    lib = prover.load_host_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(declared) <= set(prover.HOST_EXPORTS) | {"plonk_rng_next_u64", "plonk_rng_next_u32"}
+
+
 def test_no_gpu_means_an_error_not_a_fallback():
     import torch
     if torch.cuda.is_available():
