@@ -213,7 +213,20 @@ def main():
             send.copy_(torch.from_numpy(mine.view(np.int64).reshape(-1)))
             dist.all_gather_into_tensor(recv, send)
             return recv.cpu().numpy().view(np.uint64).reshape(world, count, 16)
-        pk.set_sharding(rank, world, gather)
+        collective = "torch.distributed all_gather_into_tensor (%s)" % args.dist_backend
+        if args.dist_backend == "nccl":
+            # the exchange inside the library: rank 0's RCCL id travels through torch.distributed (which stays for the rendezvous, the
+            # barriers and the timing reduction), the partial sums then go through ncclAllGather without passing through Python
+            try:
+                ids = [pk.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                pk.comm_init(ids[0], rank, world)
+                collective = "ncclAllGather inside libplonk_hip (RCCL over xGMI)"
+            except Exception as e:       # fall back to the gather above, still RCCL
+                sys.stderr.write("library communicator unavailable (%s): partial sums go through torch.distributed\n" % e)
+                pk.set_sharding(rank, world, gather)
+        else:
+            pk.set_sharding(rank, world, gather)
     pk.set_opening_challenge(synth.to_mont([0x1234567890ABCDEF1122334455667788])[0])
     inputs = pk.prepare(tables)
     blinds = synth.seeded_scalars(27, 8)
@@ -330,7 +343,7 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "synthetic 2^%d-gate random arithmetic circuit, BN254, hiding KZG10, full proof (BASELINE.json configs[2])" % log_n,
                    "log_gates": log_n, "srs_points": total, "msm_pairs_per_proof": 20 * n + 45, "ntt_per_proof": 4,
-                   "parallelism": "1 GPU" if world == 1 else "MSM sharded over %d GPUs by block-cyclic point ranges (4096 points per block), partial sums all-gathered over RCCL; other rounds replicated" % world},
+                   "parallelism": "1 GPU" if world == 1 else "MSM sharded over %d GPUs by block-cyclic point ranges (4096 points per block), partial sums exchanged by %s; other rounds replicated" % (world, collective)},
         "msm_gpts_per_s": round((20 * n + 45) / (ms_per_step * 1e-3) / 1e9, 4),
         "stage_ms": {k: round(float(v) / args.steps * 1e3, 3) for k, v in zip(["round1_commit", "grand_product", "quotient", "open", "assemble", "total"], stage)},
         "kernel_ms_per_proof": {k: round(v[0] / breakdown_steps, 3) for k, v in breakdown.items()},

@@ -231,6 +231,18 @@ int32_t plk_kzg_cancel(plk_ctx* ctx);
 /* Like *_end but returns this shard's unnormalised partial (16 limbs) instead of the affine point. */
 int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]);
 
+/* ---- multi-GPU exchange inside the library (no counterpart in the reference, which is a single process).  One process per GPU;
+ * every rank holds a shard of the SRS (plk_srs_*_cyclic), runs the same prover, and every commitment or opening is the sum of the
+ * ranks' partial sums (plk_kzg_end_partial).  Rank 0 calls plk_comm_get_unique_id and hands the 128 bytes to the other ranks by any
+ * channel (a file, MPI, a torch.distributed broadcast); every rank then calls plk_comm_init (ncclCommInitRank on this context's
+ * device; RCCL is opened at run time, so single-GPU users need no librccl).  plk_comm_all_gather_partials exchanges `count`
+ * partial sums (16 limbs each) with one ncclAllGather on the context's stream: mine[count][16] -> all[world][count][16], host
+ * arrays; plk_g1_sum_partials adds what it returns (point addition is not a reduction RCCL offers: gather, then add). */
+int32_t plk_comm_get_unique_id(uint8_t id[128]);
+int32_t plk_comm_init(plk_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
+int32_t plk_comm_destroy(plk_ctx* ctx);
+int32_t plk_comm_all_gather_partials(plk_ctx* ctx, const uint64_t* mine, uint64_t count, uint64_t* all);
+
 /* ---- scheduling hint with no counterpart in the reference (which runs everything in sequence).  The library runs NTT, pointwise and
  * scan kernels ("compute" work) on the same stream as the sorting stage of its MSMs, so that a commitment sees the polynomial the
  * call before it produced.  Between plk_compute_detach(ctx, 1) and plk_compute_detach(ctx, 0) compute work goes to a second stream

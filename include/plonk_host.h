@@ -39,6 +39,10 @@ int32_t plonk_pk_set_opening_challenge(void* pk, const uint64_t* challenge);
  * partial sums of a round (three calls per proof). */
 typedef void (*plonk_gather_fn)(void* user, const uint64_t* mine, uint64_t count, uint64_t* all);
 int32_t plonk_pk_set_sharding(void* pk, uint32_t rank, uint32_t world, plonk_gather_fn fn, void* user);
+/* the same with the exchange inside the library (ncclAllGather over RCCL / xGMI, no callback): rank 0 obtains 128 bytes from
+ * plonk_comm_get_unique_id and hands them to every rank by any channel; every rank calls plonk_pk_comm_init */
+int32_t plonk_comm_get_unique_id(uint8_t* id128);
+int32_t plonk_pk_comm_init(void* pk, const uint8_t* id128, uint32_t rank, uint32_t world);
 
 /* ---- create_plonk_proof_with_transcript (src/prover.rs:119-336; caller src/main.rs:211-221).
  * polys: a, b, c, q_add, q_mul, s_id, s_sigma (coefficient arrays, trailing zeros are stripped as DensePolynomial::from_coefficients_vec

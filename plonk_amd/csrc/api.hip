@@ -4,6 +4,7 @@
 #include "common.cuh"
 #include "host_math.hpp"
 #include "kernels.h"
+#include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -188,6 +189,7 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     prof_collect(ctx, true);
     if (ctx->prof_base) hipEventDestroy(ctx->prof_base);
     for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
+    if (ctx->comm) plk_comm_destroy(ctx);
     for (auto& s : ctx->slot) slot_destroy(s);
     ntt_release(ctx);
     hipFree(ctx->tables); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
@@ -327,6 +329,108 @@ extern "C" int32_t plk_profile_get_busy(plk_ctx* ctx, const char* name, double* 
         else if (sp.second > hi) hi = sp.second;
     }
     if (hi > lo) *busy_ms += hi - lo;
+    return PLK_OK;
+}
+
+// ---- RCCL communicator of the ranks that share one proof ---------------------------------------------------------------
+// One process per GPU; every rank holds a share of the SRS, runs the same prover and contributes a partial sum (an unnormalised
+// point of 128 bytes) to every commitment and opening.  Point addition is not a reduction RCCL offers, so the exchange is an
+// all-gather and every rank adds the partial sums itself.  RCCL is opened at run time: single-GPU users need no librccl.
+namespace {
+struct RcclId { char internal[128]; };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+bool rccl_open(std::string* why) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return true;
+    // a copy the process already holds (PyTorch brings its own) comes first: one RCCL per process is enough
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { *why = std::string("librccl not found: ") + dlerror(); return false; }
+    Rccl r;
+    r.lib = h;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) { *why = "librccl lacks an expected symbol"; return false; }
+    g_rccl = r;
+    return true;
+}
+int32_t rccl_fail(plk_ctx* ctx, const char* what, int rc) {
+    ctx->err = std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return PLK_ERR_HIP;
+}
+constexpr uint64_t COMM_MAX_POINTS = 64;    // partial sums per exchange (a round of the prover has at most nine)
+constexpr int RCCL_UINT64 = 5;              // ncclUint64
+}  // namespace
+
+extern "C" int32_t plk_comm_get_unique_id(uint8_t id[128]) {
+    if (!id) return PLK_ERR_INVALID_ARG;
+    std::string why;
+    if (!rccl_open(&why)) return PLK_ERR_HIP;
+    RcclId u;
+    if (g_rccl.GetUniqueId(&u) != 0) return PLK_ERR_HIP;
+    memcpy(id, u.internal, 128);
+    return PLK_OK;
+}
+extern "C" int32_t plk_comm_init(plk_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t world) {
+    if (!ctx || !id || world == 0 || rank >= world) return PLK_ERR_INVALID_ARG;
+    if (ctx->comm) { ctx->err = "plk_comm_init: this context already has a communicator"; return PLK_ERR_INVALID_ARG; }
+    std::string why;
+    if (!rccl_open(&why)) { ctx->err = why; return PLK_ERR_HIP; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    RcclId u;
+    memcpy(u.internal, id, 128);
+    void* comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, (int)world, u, (int)rank);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
+    PLK_HIP(hipMalloc(&ctx->comm_send, COMM_MAX_POINTS * 128));
+    PLK_HIP(hipMalloc(&ctx->comm_recv, COMM_MAX_POINTS * 128 * world));
+    PLK_HIP(hipHostMalloc(&ctx->comm_host, COMM_MAX_POINTS * 128 * (world + 1), hipHostMallocDefault));
+    return PLK_OK;
+}
+extern "C" int32_t plk_comm_destroy(plk_ctx* ctx) {
+    if (!ctx) return PLK_ERR_INVALID_ARG;
+    if (!ctx->comm) return PLK_OK;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_HIP(hipDeviceSynchronize());
+    g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    hipFree(ctx->comm_send); hipFree(ctx->comm_recv); hipHostFree(ctx->comm_host);
+    ctx->comm_send = ctx->comm_recv = nullptr; ctx->comm_host = nullptr;
+    return PLK_OK;
+}
+// mine[count][16] -> all[world][count][16] (host arrays): staged through pinned memory, ncclAllGather on the compute stream
+extern "C" int32_t plk_comm_all_gather_partials(plk_ctx* ctx, const uint64_t* mine, uint64_t count, uint64_t* all) {
+    if (!ctx || !mine || !all) return PLK_ERR_INVALID_ARG;
+    if (!ctx->comm) { ctx->err = "plk_comm_all_gather_partials: no communicator (plk_comm_init)"; return PLK_ERR_INVALID_ARG; }
+    if (count == 0) return PLK_OK;
+    if (count > COMM_MAX_POINTS) { ctx->err = "plk_comm_all_gather_partials: more than 64 points in one exchange"; return PLK_ERR_INVALID_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t bytes = count * 128, world = ctx->comm_world;
+    uint8_t* host_send = (uint8_t*)ctx->comm_host;
+    uint8_t* host_recv = host_send + COMM_MAX_POINTS * 128;
+    memcpy(host_send, mine, bytes);
+    PLK_HIP(hipMemcpyAsync(ctx->comm_send, host_send, bytes, hipMemcpyHostToDevice, st));
+    const int rc = g_rccl.AllGather(ctx->comm_send, ctx->comm_recv, count * 16, RCCL_UINT64, ctx->comm, st);
+    if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
+    PLK_HIP(hipMemcpyAsync(host_recv, ctx->comm_recv, bytes * world, hipMemcpyDeviceToHost, st));
+    PLK_HIP(hipStreamSynchronize(st));
+    memcpy(all, host_recv, bytes * world);
     return PLK_OK;
 }
 

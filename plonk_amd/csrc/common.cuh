@@ -111,6 +111,10 @@ struct plk_ctx {
     hipStream_t quotient_stream = nullptr;   // stream of a quotient enqueued with plk_quotient_dev_enqueue and not yet finished
     uint32_t* flag_dev = nullptr;
     uint32_t* flag_host = nullptr;
+    // RCCL communicator of the ranks that share one proof (plk_comm_init), with its staging buffers
+    void* comm = nullptr;
+    uint32_t comm_rank = 0, comm_world = 1;
+    void *comm_send = nullptr, *comm_recv = nullptr, *comm_host = nullptr;
     // profiling
     int profiling = 0;                 // 0 off, 1 every kernel class, 2 "msm_accumulate" only (cheap enough to stay on while a run is timed)
     bool prof_open = false;            // the last prof_begin recorded an event and waits for its prof_end

@@ -28,7 +28,7 @@ EXPORTS = [
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
     "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_dev_enqueue", "plk_quotient_dev_finish", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
-    "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_compute_detach", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
+    "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_compute_detach", "plk_comm_get_unique_id", "plk_comm_init", "plk_comm_destroy", "plk_comm_all_gather_partials", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
 ]
 
@@ -149,6 +149,27 @@ class Context:
         out = np.empty(shape, dtype=dtype)
         if out.nbytes:
             self._ck(self.lib.plk_download(self.h, _ptr(out), _vp(dptr), C.c_uint64(out.nbytes)))
+        return out
+
+    # ---- RCCL inside the library
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = self.lib.plk_comm_get_unique_id(buf)
+        if rc != 0:
+            raise PlonkHipError(rc, "plk_comm_get_unique_id failed (librccl not found?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self.lib.plk_comm_init(self.h, buf, C.c_uint32(rank), C.c_uint32(world)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.plk_comm_destroy(self.h))
+
+    def comm_all_gather_partials(self, mine: np.ndarray, world: int) -> np.ndarray:
+        m = np.ascontiguousarray(mine, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros((world, len(m), 16), dtype=np.uint64)
+        self._ck(self.lib.plk_comm_all_gather_partials(self.h, _ptr(m), C.c_uint64(len(m)), _ptr(out)))
         return out
 
     def compute_detach(self, on):

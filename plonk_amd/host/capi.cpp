@@ -45,6 +45,22 @@ int32_t plonk_pk_set_sharding(void* pk, uint32_t rank, uint32_t world, plonk_gat
     return guarded([&] { static_cast<KZGProverKey*>(pk)->set_sharding(rank, world, [fn, user](const uint64_t* m, uint64_t k, uint64_t* a) { fn(user, m, k, a); }); });
 }
 
+// Sharding with the exchange inside the library: RCCL communicator on the key's context (plk_comm_init), all-gather of the partial sums
+// through plk_comm_all_gather_partials.  id128: what rank 0 obtained from plonk_comm_get_unique_id and handed to every rank.
+int32_t plonk_comm_get_unique_id(uint8_t* id128) { return plk_comm_get_unique_id(id128); }
+int32_t plonk_pk_comm_init(void* pk, const uint8_t* id128, uint32_t rank, uint32_t world) {
+    return guarded([&] {
+        KZGProverKey* k = static_cast<KZGProverKey*>(pk);
+        plk_ctx* ctx = k->ctx();
+        const int32_t rc = plk_comm_init(ctx, id128, rank, world);
+        if (rc != PLK_OK) throw Error(rc, std::string("plk_comm_init: ") + plk_last_error(ctx));
+        k->set_sharding(rank, world, [ctx](const uint64_t* mine, uint64_t count, uint64_t* all) {
+            const int32_t rc2 = plk_comm_all_gather_partials(ctx, mine, count, all);
+            if (rc2 != PLK_OK) throw Error(rc2, std::string("plk_comm_all_gather_partials: ") + plk_last_error(ctx));
+        });
+    });
+}
+
 // polys: a, b, c, q_add, q_mul, s_id, s_sigma (coefficients, any trailing zeros are stripped as from_coefficients_vec does)
 int32_t plonk_inputs_create(void* pk, const uint64_t* const* polys, const uint64_t* lens, const uint64_t* witness_flat, const uint64_t* sigma, uint32_t log_n,
                             void** out) {

@@ -20,7 +20,7 @@ from . import hip, synth
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(hip.LIB_DIR, "libplonk_host.so")
 HOST_EXPORTS = ["plonk_host_last_error", "plonk_pk_create", "plonk_pk_destroy", "plonk_pk_ctx", "plonk_pk_load", "plonk_pk_generate", "plonk_pk_generate_cyclic",
-                "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove", "plonk_prove_host",
+                "plonk_pk_set_opening_challenge", "plonk_pk_set_sharding", "plonk_comm_get_unique_id", "plonk_pk_comm_init", "plonk_inputs_create", "plonk_inputs_destroy", "plonk_prove", "plonk_prove_host",
                 "plonk_transcript_kat", "plonk_transcript_empty_beta", "plonk_serialize_g1", "plonk_verify", "plonk_pairing_selftest", "plonk_proof_roundtrip",
                 "plonk_rng_create", "plonk_rng_destroy", "plonk_rng_next_u64", "plonk_rng_next_u32", "plonk_rng_fr", "plonk_rng_g1", "plonk_rng_g2",
                 "plonk_chacha_block", "plonk_test_sponge_challenge", "plonk_pk_setup", "plonk_prove_rng", "plonk_verify_vk", "plonk_circuit_tables"]
@@ -225,6 +225,16 @@ class ProverKey:
             C.memmove(out, res.ctypes.data, world_size * count * 16 * 8)
         self._cb = GATHER_FN(cb)
         self._ck(self.lib.plonk_pk_set_sharding(self.h, C.c_uint32(rank), C.c_uint32(world_size), self._cb, None))
+
+    def comm_unique_id(self) -> bytes:
+        """128 bytes that rank 0 hands to every rank (ncclGetUniqueId)"""
+        buf = (C.c_uint8 * 128)()
+        self._ck(self.lib.plonk_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world_size: int):
+        """set_sharding with the all-gather inside the library (RCCL), no Python in the data path"""
+        self._ck(self.lib.plonk_pk_comm_init(self.h, (C.c_uint8 * 128).from_buffer_copy(unique_id), C.c_uint32(rank), C.c_uint32(world_size)))
 
     def prepare(self, tables) -> DeviceInputs:
         """src/main.rs:79-84,187-191: interpolates q_add, q_mul, s_id, s_sigma on the GPU and uploads everything."""

@@ -424,3 +424,46 @@ def test_sharded_proof_two_processes(orc, tmp_path, layout):
     rc, want, _, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], 8, synth.seeded_scalars(27, 8), chal)
     assert rc == 0 and single == want == proofs[0]
     inputs.close(); pk.close()
+
+
+def test_library_rccl_exchange_with_one_rank(orc):
+    """plk_comm_* (ncclCommInitRank / ncclAllGather inside the library) executed with world = 1, the most one GPU allows: the
+    communicator comes up on the context's device, an all-gather returns the partial sums it was given, the sum of the gathered
+    partials is the commitment, and a key set up with plonk_pk_comm_init still proves.  More ranks need more GPUs: the combine logic
+    above the exchange is covered by the logical-shard and gloo tests."""
+    from plonk_amd.prover import ProverKey
+    pk = ProverKey(0)
+    uid = pk.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    pk.comm_init(uid, 0, 1)
+    ctx = pk.ctx
+    tau, gs = synth.seeded_scalars(2, 7)
+    pk.generate_srs(tau, gs, 4 * 256 + 1)
+    rng = np.random.default_rng(5)
+    mine = rng.integers(0, 1 << 63, size=(9, 16), dtype=np.uint64)
+    for count in (1, 2, 7, 9):
+        assert np.array_equal(ctx.comm_all_gather_partials(mine[:count], 1), mine[:count].reshape(1, count, 16))
+    coeffs = synth.seeded_scalars(300, 11); blind = synth.seeded_scalars(3, 12)
+    d = ctx.upload(coeffs)
+    t = ctx.commit_begin(d, len(coeffs), blind)
+    part = ctx.end_partial(t)
+    part = part[0] if isinstance(part, tuple) else part
+    got = ctx.comm_all_gather_partials(np.asarray(part, dtype=np.uint64).reshape(1, 16), 1)
+    xy, inf = ctx.sum_partials(got.reshape(-1, 16))
+    want, winf = ctx.kzg_commit(coeffs, blind)
+    assert inf == winf and np.array_equal(xy, want)
+    ctx.free(d)
+    # the key still proves (world = 1 takes the direct path), and a second communicator on the same context is refused
+    variables, gates = synth.synthetic_circuit(6, seed=2)
+    tables = synth.circuit_tables(variables, gates)
+    pk.set_opening_challenge(synth.to_mont([0x1234567890ABCDEF1122334455667788])[0])
+    inputs = pk.prepare(tables)
+    blinds = synth.seeded_scalars(27, 8)
+    a = pk.prove(inputs, blinds)
+    from plonk_amd.hip import PlonkHipError
+    with pytest.raises(PlonkHipError):
+        pk.comm_init(uid, 0, 1)
+    b = pk.prove(inputs, blinds)
+    assert a.proof_bytes == b.proof_bytes
+    inputs.close()
+    pk.close()
