@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--log-gates", type=int, default=20)
     ap.add_argument("--cpu-log-gates", type=int, default=18, help="size of the single-thread CPU-baseline sample (0 = skip; the all-cores figure is measured at full size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-incl-h2d", action="store_true", help="skip the host-arrays-in measurement (value_incl_h2d_ms)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ntt-log-n", type=int, default=24, help="size of the standalone coset NTT reported beside the proof (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL over xGMI, one rank per GPU) or gloo (rehearsal with several ranks on one GPU)")
@@ -262,7 +263,7 @@ def main():
     # The same proof with the reference's call shape (src/prover.rs:119-133 borrows host vectors): host arrays in, proof out, the
     # transfers (a, b, c, q_add, q_mul, s_id, s_sigma, witness_flat, sigma) inside the timed region.  Never `value`: reported beside it.
     incl = None
-    if world == 1:
+    if world == 1 and not args.no_incl_h2d:
         pk.ctx.profile_enable(0)
         host_arrays = [np.ascontiguousarray(p) for p in inputs.polys] + [np.ascontiguousarray(tables["witness_flat"], dtype=np.uint64),
                                                                          np.ascontiguousarray(tables["sigma"], dtype=np.uint64)]

@@ -82,12 +82,13 @@ static int32_t grow(plk_ctx* ctx, hipStream_t st, uint32_t** buf, uint64_t* cap,
 }
 
 // orders the sort stream (the entry of the MSM pipeline) after everything already enqueued on the compute stream
-static int32_t sort_after_compute(plk_ctx* ctx) {
+static int32_t sort_after_compute(plk_ctx* ctx, hipStream_t lane) {
     if (ctx->detached) return PLK_OK;   // the caller promised that this job's inputs do not come from the detached compute work
+    if (lane == ctx->stream) return PLK_OK;
     hipEvent_t ev;
     PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     PLK_HIP(hipEventRecord(ev, ctx->stream));
-    PLK_HIP(hipStreamWaitEvent(ctx->st_sort, ev, 0));
+    PLK_HIP(hipStreamWaitEvent(lane, ev, 0));
     PLK_HIP(hipEventDestroy(ev));
     return PLK_OK;
 }
@@ -225,6 +226,7 @@ extern "C" int32_t plk_upload_enqueue(plk_ctx* ctx, void* dev_dst, const void* h
     if (!ctx || (bytes && (!dev_dst || !host_src))) return PLK_ERR_INVALID_ARG;
     if (!bytes) return PLK_OK;
     PLK_HIP(hipSetDevice(ctx->device));
+    ctx->uploads_pending = true;
     PLK_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->st_red));
     hipEvent_t ev;
     PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -441,10 +443,11 @@ extern "C" int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, ui
     int si;
     PLK_TRY(msm_acquire_slot(ctx, &si));
     MsmSlot& s = ctx->slot[si];
-    PLK_TRY(sort_after_compute(ctx));
+    hipStream_t lane = front_lane(ctx);
+    PLK_TRY(sort_after_compute(ctx, lane));
     memcpy(s.blind_host, blind, 96);
-    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 96, hipMemcpyHostToDevice, ctx->st_sort));
-    PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)coeffs_dev, len, 0, 3));
+    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 96, hipMemcpyHostToDevice, lane));
+    PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)coeffs_dev, len, 0, 3, lane));
     s.busy = true; s.kind = 1;
     *ticket = si;
     return PLK_OK;
@@ -452,6 +455,7 @@ extern "C" int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, ui
 extern "C" int32_t plk_kzg_submit(plk_ctx* ctx) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
+    ctx->uploads_pending = false;
     return msm_flush_reductions(ctx);
 }
 extern "C" int32_t plk_kzg_ready(plk_ctx* ctx, int32_t ticket, int32_t* ready) {
@@ -521,13 +525,14 @@ extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint
     MsmSlot& s = ctx->slot[si];
     PLK_TRY(grow(ctx, ctx->st_sort, &s.scal_dev, &s.scal_cap, (len + 1) * 8));
     PLK_TRY(grow(ctx, ctx->st_sort, &s.chain_dev, &s.chain_cap, division_work_words(len)));
-    PLK_TRY(sort_after_compute(ctx));
+    hipStream_t lane = front_lane(ctx);
+    PLK_TRY(sort_after_compute(ctx, lane));
     // witness polynomial of challenge*f: scalars challenge * h_i, i >= 1; h_0 = f(zeta)
     // a contiguous shard needs its own range of quotient coefficients only, a block-cyclic one has a part in every stretch
     const bool cyclic = ctx->cyc_world > 1;
-    PLK_TRY(division_enqueue(ctx, ctx->st_sort, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev,
+    PLK_TRY(division_enqueue(ctx, lane, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev,
                              cyclic ? 0 : ctx->shard_first, cyclic ? len : ctx->shard_len));
-    PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, ctx->st_sort));
+    PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, lane));
     // hiding part on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2, random_v = r'(zeta)
     using namespace host;
     const el z = el_load(zeta), ch = el_load(challenge);
@@ -537,8 +542,8 @@ extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint
     memcpy(s.host_rv, rv.v, 32);
     memcpy(s.blind_host, hw0.v, 32);
     memcpy(s.blind_host + 8, hw1.v, 32);
-    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 64, hipMemcpyHostToDevice, ctx->st_sort));
-    PLK_TRY(msm_enqueue(ctx, s, s.scal_dev, len >= 2 ? len - 1 : 0, 0, 2));
+    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 64, hipMemcpyHostToDevice, lane));
+    PLK_TRY(msm_enqueue(ctx, s, s.scal_dev, len >= 2 ? len - 1 : 0, 0, 2, lane));
     s.busy = true; s.kind = 2;
     *ticket = si;
     return PLK_OK;

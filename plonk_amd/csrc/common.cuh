@@ -89,6 +89,8 @@ struct plk_ctx {
     // reduction + read-back on st_red: the accumulation kernels (most of a proof) run back to back while the
     // latency-bound stages of their neighbours fill in beside them.
     hipStream_t st_sort = nullptr, st_acc[2] = {nullptr, nullptr}, st_red = nullptr;
+    unsigned lane_turn = 0;            // front_lane(): whose turn it is
+    bool uploads_pending = false;      // plk_upload_enqueue since the last plk_kzg_submit: transfers queue on st_red, sorts keep off it
     bool detached = false;             // plk_compute_detach: `stream` is st_red for the time being, so compute work runs beside the sorts on st_sort
     uint64_t acc_load[2] = {0, 0};     // entries queued on each accumulation stream since the device was last idle
     plk::MsmSlot slot[plk::MSM_SLOTS];

@@ -7,7 +7,13 @@ namespace plk {
 
 // msm.hip
 int32_t msm_acquire_slot(plk_ctx* ctx, int* out);
-int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind);
+// lane: the stream that carries this MSM's sort (front_lane(); nullptr = the context's front stream)
+int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind, hipStream_t lane = nullptr);
+// Stream for the front work (division, sort) of the next commitment or opening.  The front work of consecutive jobs alternates between
+// the front stream and the reduction stream, so that the sort of one job runs beside the sort of the next: on one stream the sorts
+// (latency-bound, a fraction of the chip each) follow each other and feed the accumulation kernels too slowly.  One stream while
+// compute work is detached to the reduction stream or uploads are queued on it.
+hipStream_t front_lane(plk_ctx* ctx);
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);   // enqueues the pending reductions first
 int32_t msm_flush_reductions(plk_ctx* ctx);
 void slot_destroy(MsmSlot& s);

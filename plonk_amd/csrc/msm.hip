@@ -172,6 +172,136 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(MsmSegs segs, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------ two-level sort
+// The one-level scatter above hands every (chunk, bucket) pair its own few slots, so each 4-byte store lands in a line that no
+// other store of the same workgroup completes soon: the line leaves the L2 with four valid bytes and memory sees one partial write
+// per entry.  Here the entries first go to SORT_PARTS = 256 partitions by the upper eight bits of their bucket (8-byte records:
+// entry word + lower seven bits), each workgroup appending to its own reserved piece of a partition, so the 256 lines it has open
+// fill within an iteration or two; then one workgroup per partition spreads its records over the partition's 128 buckets, all
+// inside a region of about 256 KB that stays in the L2 until its lines are full.  Three launches; 1 KB of LDS per workgroup.
+constexpr int SORT_PARTS = 256, SORT_PART_BUCKETS = MSM_BUCKETS / SORT_PARTS;   // 128 buckets per partition
+static_assert(SORT_PART_BUCKETS == 128, "records keep seven bucket bits");
+// digits of every scalar (codes as in k_msm_digits) + this workgroup's histogram of partitions -> part_counts[workgroup][SORT_PARTS]
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ digits, uint32_t* __restrict__ part_counts) {
+    PLK_SIDE_PRIO();
+    __shared__ uint32_t hist[SORT_PARTS];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, segs.total);
+    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
+        uint32_t ti;
+        const uint32_t* sp = seg_scalar(segs, idx, &ti);
+        int32_t d[MSM_WINDOWS];
+        scalar_digits(sp, d);
+        uint32_t w[MSM_WINDOWS / 2];
+#pragma unroll
+        for (int j = 0; j < MSM_WINDOWS; j += 2) {
+            const uint32_t c0 = d[j] == 0 ? DIGIT_NONE : ((d[j] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1));
+            const uint32_t c1 = d[j + 1] == 0 ? DIGIT_NONE : ((d[j + 1] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j + 1] < 0 ? -d[j + 1] : d[j + 1]) - 1));
+            w[j / 2] = c0 | (c1 << 16);
+            if (c0 != DIGIT_NONE) atomicAdd(&hist[(c0 & 0x7fffu) >> 7], 1u);
+            if (c1 != DIGIT_NONE) atomicAdd(&hist[(c1 & 0x7fffu) >> 7], 1u);
+        }
+        store8(digits + 8ull * idx, w);
+    }
+    __syncthreads();
+    part_counts[(size_t)blockIdx.x * SORT_PARTS + threadIdx.x] = hist[threadIdx.x];
+}
+// records[slot] = entry word | (lower seven bucket bits << 32), appended to this workgroup's piece of the record's partition
+// Every workgroup works out where its pieces begin from the whole count matrix (nblocks x 256 words, read from the L2): thread p sums
+// partition p over all workgroups (the partition's size) and over the workgroups before its own, a scan over p gives the
+// partition's start.  A kernel of its own for this took one more launch and, as a single workgroup beside the accumulation waves,
+// as long as the partitioning itself.  Workgroup 0 also publishes the partition starts for k_sort_buckets.
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(MsmSegs segs, uint32_t chunk, const uint32_t* __restrict__ digits, const uint32_t* __restrict__ part_counts,
+                                                                 uint32_t nblocks, uint32_t* __restrict__ part_start, uint32_t table_stride, uint64_t* __restrict__ records) {
+    PLK_SIDE_PRIO();
+    __shared__ uint32_t cursor[SORT_PARTS];
+    __shared__ uint32_t wave_sum[SORT_THREADS / 64];
+    {
+        const uint32_t p = threadIdx.x, lane = p & 63, wave = p >> 6;
+        uint32_t total = 0, before = 0;
+        for (uint32_t k = 0; k < nblocks; ++k) {
+            const uint32_t c = part_counts[(size_t)k * SORT_PARTS + p];
+            total += c;
+            before += k < blockIdx.x ? c : 0;
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += x; }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t start = incl - total;
+        for (uint32_t k = 0; k < wave; ++k) start += wave_sum[k];
+        cursor[p] = start + before;
+        if (blockIdx.x == 0) {
+            part_start[p] = start;
+            if (p == SORT_PARTS - 1) part_start[SORT_PARTS] = start + total;
+        }
+    }
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, segs.total);
+    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
+        uint32_t ti;
+        (void)seg_scalar(segs, idx, &ti);
+        uint32_t w[8];
+        load8(digits + 8ull * idx, w);
+#pragma unroll
+        for (int j = 0; j < MSM_WINDOWS; ++j) {
+            const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (code == DIGIT_NONE) continue;
+            const uint32_t b = code & 0x7fffu;
+            const uint32_t slot = atomicAdd(&cursor[b >> 7], 1u);
+            const uint32_t entry = ((code & 0x8000u) << 16) | ((uint32_t)j * table_stride + ti);
+            records[slot] = (uint64_t)entry | ((uint64_t)(b & 127u) << 32);
+        }
+    }
+}
+// one workgroup per partition: bucket sizes, bucket starts, then the entries in bucket order
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_buckets(const uint64_t* __restrict__ records, const uint32_t* __restrict__ part_start,
+                                                               uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ entries) {
+    PLK_SIDE_PRIO();
+    __shared__ uint32_t cnt[SORT_PART_BUCKETS];
+    __shared__ uint32_t wave_sum[2];
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const uint32_t first = part_start[p], last = part_start[p + 1];
+    if (t < SORT_PART_BUCKETS) cnt[t] = 0;
+    __syncthreads();
+    // four records per thread and step, so that four loads are in flight instead of one
+    for (uint32_t i = first + t; i < last; i += 4 * SORT_THREADS) {
+        uint64_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = i + k * SORT_THREADS < last ? records[i + k * SORT_THREADS] : ~0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (r[k] != ~0ull) atomicAdd(&cnt[(uint32_t)(r[k] >> 32)], 1u);
+    }
+    __syncthreads();
+    {                                   // exclusive scan of the 128 counters (the first two waves hold them)
+        const uint32_t lane = t & 63, wave = t >> 6, c = t < SORT_PART_BUCKETS ? cnt[t] : 0;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += x; }
+        if (lane == 63 && wave < 2) wave_sum[wave] = incl;
+        __syncthreads();
+        if (t < SORT_PART_BUCKETS) {
+            const uint32_t start = first + incl - c + (wave ? wave_sum[0] : 0);
+            bucket_start[p * SORT_PART_BUCKETS + t] = start;
+            cnt[t] = start;             // from here on: the next free slot of the bucket
+        }
+    }
+    if (p == SORT_PARTS - 1 && t == 0) bucket_start[MSM_BUCKETS] = last;
+    __syncthreads();
+    for (uint32_t i = first + t; i < last; i += 4 * SORT_THREADS) {
+        uint64_t r[4];
+        uint32_t at[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = i + k * SORT_THREADS < last ? records[i + k * SORT_THREADS] : ~0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) at[k] = r[k] != ~0ull ? atomicAdd(&cnt[(uint32_t)(r[k] >> 32)], 1u) : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (r[k] != ~0ull) entries[at[k]] = (uint32_t)r[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ buckets
 // The accumulation kernel keeps two waves of up to 176 registers on every SIMD (352 of 512).  Kernels of neighbouring MSMs
 // that must run beside it are held to the remaining 160, otherwise their waves wait for an accumulation wave to retire and
@@ -477,7 +607,7 @@ static int32_t slots_reserve(plk_ctx* ctx) {
     const uint64_t scal_words = (ctx->srs_total + 1) * 8, chain_words = division_work_words(ctx->srs_total);
     for (auto& s : ctx->slot) {
         PLK_TRY(slot_init(ctx, s));
-        if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 6)); s.entries_cap = entries; }   // 4 bytes per entry + 2 per digit code
+        if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 14)); s.entries_cap = entries; }   // per entry: 4 bytes sorted entry + 2 digit code + 8 record of the two-level sort
         PLK_TRY(tails_reserve(ctx, s, acc_lanes(entries, acc_run(entries))));
         if (s.scal_cap < scal_words) { if (s.scal_dev) PLK_HIP(hipFree(s.scal_dev)); s.scal_dev = nullptr; s.scal_cap = 0; PLK_HIP(hipMalloc(&s.scal_dev, scal_words * 4)); s.scal_cap = scal_words; }
         if (s.chain_cap < chain_words) { if (s.chain_dev) PLK_HIP(hipFree(s.chain_dev)); s.chain_dev = nullptr; s.chain_cap = 0; PLK_HIP(hipMalloc(&s.chain_dev, chain_words * 4)); s.chain_cap = chain_words; }
@@ -536,7 +666,12 @@ static void clip_to_shard(const plk_ctx* ctx, const uint32_t* scalars, uint64_t 
 
 // Enqueues one MSM on the slot's stream: main segment (device scalars over powers_of_g) plus, when n_blind > 0 and this
 // shard holds the gamma powers, n_blind scalars (already in slot.blind_dev) over powers_of_gamma_g.
-int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind) {
+hipStream_t front_lane(plk_ctx* ctx) {
+    static const bool single = getenv("PLK_ONE_LANE") != nullptr;
+    if (single || ctx->detached || ctx->uploads_pending) return ctx->st_sort;
+    return (ctx->lane_turn++ & 1) ? ctx->st_red : ctx->st_sort;
+}
+int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind, hipStream_t lane) {
     if (!ctx->tables) { ctx->err = "no SRS loaded"; return PLK_ERR_INVALID_ARG; }
     if (base_offset + k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
     MsmSegs segs;
@@ -552,7 +687,7 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         if (s.entries) PLK_HIP(hipFree(s.entries));
         s.entries = nullptr; s.entries_cap = 0;
         const uint64_t cap = (max_entries + max_entries / 8 + 1024 + 15) & ~15ull;   // the digit codes behind the entries are stored 16 bytes at a time
-        PLK_HIP(hipMalloc(&s.entries, cap * 6));   // 4 bytes per entry + 2 per digit code
+        PLK_HIP(hipMalloc(&s.entries, cap * 14));   // 4 bytes per entry + 2 per digit code + 8 per record
         s.entries_cap = cap;
     }
     PLK_TRY(tails_reserve(ctx, s, acc_lanes(max_entries, acc_run(max_entries))));
@@ -568,9 +703,23 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     if (nblocks < 1) nblocks = 1;
     if (nblocks > (uint32_t)MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
     const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
-    hipStream_t st = ctx->st_sort;
+    hipStream_t st = lane ? lane : ctx->st_sort;
     prof_begin(ctx, st, "msm_sort");
     uint32_t* digits = s.entries + s.entries_cap;      // 16 two-byte codes per scalar, at most entries_cap of them
+    static const bool one_level = getenv("PLK_SORT_ONE_LEVEL") != nullptr;   // the earlier sort, kept for comparison
+    if (!one_level) {
+        uint64_t* records = reinterpret_cast<uint64_t*>(s.entries + s.entries_cap + s.entries_cap / 2);
+        uint32_t per = 8192;
+        while (per > 1024 && (segs.total + per - 1) / per < 128) per >>= 1;
+        uint32_t nb = (segs.total + per - 1) / per;
+        if (nb < 1) nb = 1;
+        if (nb > (uint32_t)MSM_MAX_BLOCKS) nb = MSM_MAX_BLOCKS;
+        const uint32_t ch = (segs.total + nb - 1) / nb;
+        uint32_t* part_start = s.totals;               // SORT_PARTS + 1 words (the buffer holds MSM_BUCKETS)
+        hipLaunchKernelGGL(k_sort_digits_count, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts);
+        hipLaunchKernelGGL(k_sort_partition, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts, nb, part_start, (uint32_t)ctx->table_stride, records);
+        hipLaunchKernelGGL(k_sort_buckets, dim3(SORT_PARTS), dim3(SORT_THREADS), 0, st, records, part_start, s.bucket_start, s.entries);
+    } else {
     if (segs.total) hipLaunchKernelGGL(k_msm_digits, dim3((segs.total + 255) / 256), dim3(256), 0, st, segs, digits);
     hipLaunchKernelGGL(k_msm_count, dim3(nblocks, split), dim3(SORT_THREADS), (MSM_BUCKETS >> log_split) * 4, st, digits, segs.total, chunk, s.counts, log_split);
     hipLaunchKernelGGL(k_msm_totals, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.totals);
@@ -578,6 +727,7 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     hipLaunchKernelGGL(k_msm_offsets, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.bucket_start);
     hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks, split), dim3(SORT_THREADS), (MSM_BUCKETS >> log_split) * 4, st, segs, digits, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries,
                        log_split);
+    }
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.sorted, st));
     // The accumulation goes to the stream with less work queued (entries of the jobs enqueued since the device was last idle): the kernel
