@@ -17,11 +17,11 @@ pmc() {     # name, counter, command...
     timeout -s KILL 300 rocprofv3 --pmc $ctr --output-format csv -d $out/${name}_$ctr -o p -- "$@" > /dev/null 2> $out/${name}_$ctr.err
     python3 tools/pmc_summary.py $(find $out/${name}_$ctr -name "*counter_collection.csv" | head -1) > $out/${name}_pmc_$ctr.txt
 }
-stats bench20 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
+stats bench20 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-incl-h2d
 stats ntt24 python3 tools/bench_msm.py --log-n 24 --reps 5 --ntt
 stats quotient22 python3 tools/bench_msm.py --log-n 22 --reps 5 --quotient
 for c in FETCH_SIZE WRITE_SIZE; do
-    pmc bench20 $c python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --ntt-log-n 0
+    pmc bench20 $c python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-incl-h2d --ntt-log-n 0
     pmc ntt24 $c python3 tools/bench_msm.py --log-n 24 --reps 2 --ntt
     pmc quotient22 $c python3 tools/bench_msm.py --log-n 22 --reps 2 --quotient
 done
