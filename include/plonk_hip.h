@@ -136,6 +136,13 @@ int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_dev, const 
  * z_vals = domain.fft(&z_poly.coeffs) (src/prover.rs:237) are exactly these, so the forward transform can be skipped. */
 int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n,
                                      const uint64_t beta[4], const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev);
+/* The same without the final wait: the errors the call can report are known when it returns, the last kernels are still running on
+ * the compute stream.  Commitments, plk_compute_detach and compute calls issued afterwards are ordered behind them; a host read of
+ * the outputs needs plk_sync first.  z_coeffs_out_dev may be NULL: values only, no interpolation (the caller interpolates a copy
+ * with plk_ntt_dev_enqueue).  Lets the prover start round 3 (src/prover.rs:224-259), which reads the values, beside the
+ * interpolation and the sort of z (:208-216). */
+int32_t plk_grand_product_dev_enqueue(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n,
+                                      const uint64_t beta[4], const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev);
 
 /* ---- Circuit::build_quotient_polynomial (src/circuit.rs:442-489) incl. build_permutation_constraint (:343-405)
  * and the all-zero public-input polynomial of src/prover.rs:224-227.  Columns are values on H (n each).
@@ -251,7 +258,9 @@ int32_t plk_comm_all_gather_partials(plk_ctx* ctx, const uint64_t* mine, uint64_
  * the detached work after everything enqueued before; re-attaching orders everything after it.  In between the caller guarantees
  * that no *_begin call reads what a detached compute call writes.  on = 2 re-attaches WITHOUT ordering later calls after the
  * detached work (it keeps running beside them; only detached work enqueued later, or work after a later plk_compute_detach(ctx, 0),
- * may read its results).  Results never depend on this call, only timing does. */
+ * may read its results).  on = 3 detaches WITHOUT ordering the detached work after what was enqueued since the last detach: for a
+ * caller who detached once to fix the order (on = 1), re-attached (on = 2), enqueued attached work that the detached work does not
+ * read, and now goes on with detached work.  Results never depend on this call, only timing does. */
 int32_t plk_compute_detach(plk_ctx* ctx, int32_t on);
 /* plk_quotient_dev in two halves, so that the host can enqueue other work while the quotient's kernels run:
  * _enqueue launches them (on the compute stream, detached or not) and returns; _finish waits and reports as plk_quotient_dev does. */

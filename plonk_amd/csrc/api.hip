@@ -273,10 +273,11 @@ static int32_t order_streams(plk_ctx* ctx, hipStream_t first, hipStream_t then) 
 extern "C" int32_t plk_compute_detach(plk_ctx* ctx, int32_t on) {
     if (!ctx) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
-    if (on < 0 || on > 2) return PLK_ERR_INVALID_ARG;
-    if ((on == 1) == ctx->detached) return PLK_OK;
-    if (on == 1) {
-        PLK_TRY(order_streams(ctx, ctx->st_sort, ctx->st_red));   // detached work may read what earlier calls produced
+    if (on < 0 || on > 3) return PLK_ERR_INVALID_ARG;
+    const bool detach = on == 1 || on == 3;
+    if (detach == ctx->detached) return PLK_OK;
+    if (detach) {
+        if (on == 1) PLK_TRY(order_streams(ctx, ctx->st_sort, ctx->st_red));   // detached work may read what earlier calls produced
         ctx->stream = ctx->st_red;
         ctx->detached = true;
     } else {

@@ -220,7 +220,15 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(MsmSegs segs, u
     {
         const uint32_t p = threadIdx.x, lane = p & 63, wave = p >> 6;
         uint32_t total = 0, before = 0;
-        for (uint32_t k = 0; k < nblocks; ++k) {
+        uint32_t k = 0;
+        for (; k + 16 <= nblocks; k += 16) {   // sixteen loads in flight instead of one
+            uint32_t c[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u] = part_counts[(size_t)(k + u) * SORT_PARTS + p];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { total += c[u]; before += k + u < blockIdx.x ? c[u] : 0; }
+        }
+        for (; k < nblocks; ++k) {
             const uint32_t c = part_counts[(size_t)k * SORT_PARTS + p];
             total += c;
             before += k < blockIdx.x ? c : 0;
@@ -256,9 +264,12 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(MsmSegs segs, u
         }
     }
 }
-// one workgroup per partition: bucket sizes, bucket starts, then the entries in bucket order
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_buckets(const uint64_t* __restrict__ records, const uint32_t* __restrict__ part_start,
-                                                               uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ entries) {
+// one workgroup per partition: bucket sizes, bucket starts, then the entries in bucket order.  T threads: 256 beside accumulation
+// kernels (a four-wave workgroup finds room on a busy CU), 1024 when the chip is idle (the first sort of a round: every CU has one
+// partition to itself and nothing else to do, so sixteen waves go through its records four times as fast).
+template <int T>
+__global__ void __launch_bounds__(T) k_sort_buckets(const uint64_t* __restrict__ records, const uint32_t* __restrict__ part_start,
+                                                    uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ entries) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t cnt[SORT_PART_BUCKETS];
     __shared__ uint32_t wave_sum[2];
@@ -267,10 +278,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_buckets(const uint64_t* _
     if (t < SORT_PART_BUCKETS) cnt[t] = 0;
     __syncthreads();
     // four records per thread and step, so that four loads are in flight instead of one
-    for (uint32_t i = first + t; i < last; i += 4 * SORT_THREADS) {
+    for (uint32_t i = first + t; i < last; i += 4 * T) {
         uint64_t r[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = i + k * SORT_THREADS < last ? records[i + k * SORT_THREADS] : ~0ull;
+        for (int k = 0; k < 4; ++k) r[k] = i + k * T < last ? records[i + k * T] : ~0ull;
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (r[k] != ~0ull) atomicAdd(&cnt[(uint32_t)(r[k] >> 32)], 1u);
     }
@@ -290,11 +301,11 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_buckets(const uint64_t* _
     }
     if (p == SORT_PARTS - 1 && t == 0) bucket_start[MSM_BUCKETS] = last;
     __syncthreads();
-    for (uint32_t i = first + t; i < last; i += 4 * SORT_THREADS) {
+    for (uint32_t i = first + t; i < last; i += 4 * T) {
         uint64_t r[4];
         uint32_t at[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = i + k * SORT_THREADS < last ? records[i + k * SORT_THREADS] : ~0ull;
+        for (int k = 0; k < 4; ++k) r[k] = i + k * T < last ? records[i + k * T] : ~0ull;
 #pragma unroll
         for (int k = 0; k < 4; ++k) at[k] = r[k] != ~0ull ? atomicAdd(&cnt[(uint32_t)(r[k] >> 32)], 1u) : 0;
 #pragma unroll
@@ -444,7 +455,12 @@ __device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
             else acc = xyzz_add(acc, ld_tail(tails, tail_stride, m_hi));   // the final, shorter run
         }
     }
-    for (int s = FOLD_LANES / 2; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
+    // only the lanes whose partner belongs to the same bucket add: a lane past the end of the wave would receive its own value back,
+    // take the doubling branch, and the whole wave would execute that branch beside the addition at every level
+    for (int s = FOLD_LANES / 2; s > 0; s >>= 1) {
+        const xyzz other = shfl_down_xyzz(acc, s);
+        if (j < (uint32_t)s) acc = xyzz_add(acc, other);
+    }
     if (j == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
 }
 
@@ -495,7 +511,10 @@ __device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb) {
     xyzz acc = xyzz_inf();
 #pragma unroll 1
     for (uint32_t k = lane; k < count; k += 64) acc = xyzz_add(acc, ld_xyzz(part + (size_t)(first + k) * XYZZ_WORDS));
-    for (int s = 32; s > 0; s >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, s));
+    for (int s = 32; s > 0; s >>= 1) {   // as in the fold: lanes without a partner must not add their own value
+        const xyzz other = shfl_down_xyzz(acc, s);
+        if (lane < (uint32_t)s) acc = xyzz_add(acc, other);
+    }
     if (lane == 0) {
         uint32_t* dst = out + (size_t)o * 32;
         const fe to_r = fe_const(FqP::TO_R);
@@ -579,7 +598,7 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
 // Entries per lane of the accumulation kernel: close to 64, chosen so that the launch is a whole number of chip-wide rounds
 // (256 CUs x 4 SIMDs x 2 waves x 64 lanes), never below 16.
 static uint32_t acc_run(uint64_t max_entries) {
-    const uint64_t target = 64;
+    const uint64_t target = 64;   // measured inside a proof of 2^20 gates: 48 +0.25 ms, 96 +0.4 ms, 128 +0.55 ms
     const uint64_t chip = 256ull * 4 * 2 * 64;
     uint64_t rounds = (max_entries + chip * target / 2) / (chip * target);
     if (rounds < 1) rounds = 1;
@@ -704,6 +723,8 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     if (nblocks > (uint32_t)MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
     const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
     hipStream_t st = lane ? lane : ctx->st_sort;
+    bool idle = ctx->reduce_pending.empty();   // nothing of this context is running or queued on the device
+    for (const auto& other : ctx->slot) idle = idle && (!other.busy || &other == &s);
     prof_begin(ctx, st, "msm_sort");
     uint32_t* digits = s.entries + s.entries_cap;      // 16 two-byte codes per scalar, at most entries_cap of them
     static const bool one_level = getenv("PLK_SORT_ONE_LEVEL") != nullptr;   // the earlier sort, kept for comparison
@@ -713,7 +734,10 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         // (every workgroup of the partitioning kernel reads the whole count matrix).  Measured inside a proof of 2^20 gates: 4096 scalars
         // per workgroup the same, 16384 0.6 ms slower; four workgroups per partition in the second level (1024 workgroups, two launches)
         // halve the isolated sort and make the proof 0.7 ms slower; without the raised issue priority 0.9 ms slower.
-        uint32_t per = 8192;
+        // The first sort of a round finds the chip idle and the round waiting for it: twice as many workgroups in the first level,
+        // sixteen waves per partition in the second (0.2 ms per proof).
+        const bool fast = idle;
+        uint32_t per = fast ? 4096 : 8192;
         while (per > 1024 && (segs.total + per - 1) / per < 128) per >>= 1;
         uint32_t nb = (segs.total + per - 1) / per;
         if (nb < 1) nb = 1;
@@ -722,7 +746,8 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         uint32_t* part_start = s.totals;               // SORT_PARTS + 1 words (the buffer holds MSM_BUCKETS)
         hipLaunchKernelGGL(k_sort_digits_count, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts);
         hipLaunchKernelGGL(k_sort_partition, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts, nb, part_start, (uint32_t)ctx->table_stride, records);
-        hipLaunchKernelGGL(k_sort_buckets, dim3(SORT_PARTS), dim3(SORT_THREADS), 0, st, records, part_start, s.bucket_start, s.entries);
+        if (fast) hipLaunchKernelGGL(k_sort_buckets<1024>, dim3(SORT_PARTS), dim3(1024), 0, st, records, part_start, s.bucket_start, s.entries);
+        else hipLaunchKernelGGL(k_sort_buckets<SORT_THREADS>, dim3(SORT_PARTS), dim3(SORT_THREADS), 0, st, records, part_start, s.bucket_start, s.entries);
     } else {
     if (segs.total) hipLaunchKernelGGL(k_msm_digits, dim3((segs.total + 255) / 256), dim3(256), 0, st, segs, digits);
     hipLaunchKernelGGL(k_msm_count, dim3(nblocks, split), dim3(SORT_THREADS), (MSM_BUCKETS >> log_split) * 4, st, digits, segs.total, chunk, s.counts, log_split);
@@ -736,8 +761,6 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     PLK_HIP(hipEventRecord(s.sorted, st));
     // The accumulation goes to the stream with less work queued (entries of the jobs enqueued since the device was last idle): the kernel
     // behind a long one would otherwise wait for it to drain completely while the other stream has nothing left to run.
-    bool idle = ctx->reduce_pending.empty();
-    for (const auto& other : ctx->slot) idle = idle && (!other.busy || &other == &s);
     if (idle) ctx->acc_load[0] = ctx->acc_load[1] = 0;
     const int acc_stream = ctx->acc_load[1] < ctx->acc_load[0] ? 1 : 0;
     ctx->acc_load[acc_stream] += max_entries + 65536;   // a launch costs something even when it is empty

@@ -597,9 +597,22 @@ extern "C" int32_t plk_grand_product_dev(plk_ctx* ctx, const void* witness_flat_
                                          const uint64_t gamma[4], void* z_coeffs_out_dev) {
     return plk_grand_product_values_dev(ctx, witness_flat_dev, sigma_dev, log_n, beta, gamma, nullptr, z_coeffs_out_dev);
 }
+// wait == false: returns with the last kernels (values -> coefficients) still running on the compute stream
+static int32_t grand_product(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                             void* z_vals_out_dev, void* z_coeffs_out_dev, bool wait);
 extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
                                                 const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev) {
-    if (!ctx || !witness_flat_dev || !sigma_dev || !beta || !gamma || !z_coeffs_out_dev || log_n > 26) return PLK_ERR_INVALID_ARG;
+    return grand_product(ctx, witness_flat_dev, sigma_dev, log_n, beta, gamma, z_vals_out_dev, z_coeffs_out_dev, true);
+}
+extern "C" int32_t plk_grand_product_dev_enqueue(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4],
+                                                 const uint64_t gamma[4], void* z_vals_out_dev, void* z_coeffs_out_dev) {
+    return grand_product(ctx, witness_flat_dev, sigma_dev, log_n, beta, gamma, z_vals_out_dev, z_coeffs_out_dev, false);
+}
+static int32_t grand_product(plk_ctx* ctx, const void* witness_flat_dev, const void* sigma_dev, uint32_t log_n, const uint64_t beta[4], const uint64_t gamma[4],
+                             void* z_vals_out_dev, void* z_coeffs_out_dev, bool wait) {
+    // the variant that does not wait may leave out the coefficients (values only, no interpolation)
+    if (!ctx || !witness_flat_dev || !sigma_dev || !beta || !gamma || log_n > 26) return PLK_ERR_INVALID_ARG;
+    if (!z_coeffs_out_dev && (wait || !z_vals_out_dev)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
     hipStream_t st = ctx->stream;
@@ -626,11 +639,13 @@ extern "C" int32_t plk_grand_product_values_dev(plk_ctx* ctx, const void* witnes
     if (host::is_zero(d)) { ctx->err = "grand product: denominator is zero"; return PLK_ERR_INVERSE_OF_ZERO; }
     const host::el dinv = host::mul(host::FR, host::inv(host::FR, d), host::from_u64(host::FR, 32));
     prof_begin(ctx, st, "pointwise");
-    hipLaunchKernelGGL(k_gp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, num, den, n, w8_of(dinv), (uint32_t*)z_coeffs_out_dev);
+    hipLaunchKernelGGL(k_gp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, num, den, n, w8_of(dinv), (uint32_t*)(z_coeffs_out_dev ? z_coeffs_out_dev : z_vals_out_dev));
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
+    if (!z_coeffs_out_dev) return PLK_OK;
     if (z_vals_out_dev) PLK_HIP(hipMemcpyAsync(z_vals_out_dev, z_coeffs_out_dev, n * 32, hipMemcpyDeviceToDevice, st));   // z on H, before the interpolation
     PLK_TRY(ntt_run(ctx, st, (uint32_t*)z_coeffs_out_dev, log_n, true, nullptr));
+    if (!wait) return PLK_OK;
     PLK_HIP(hipStreamSynchronize(st));
     prof_collect(ctx, false);
     return PLK_OK;

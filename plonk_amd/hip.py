@@ -26,7 +26,7 @@ EXPORTS = [
     "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
-    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_dev_enqueue", "plk_quotient_dev_finish", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
+    "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_grand_product_dev_enqueue", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_dev_enqueue", "plk_quotient_dev_finish", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
     "plk_kzg_open_begin", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_compute_detach", "plk_comm_get_unique_id", "plk_comm_init", "plk_comm_destroy", "plk_comm_all_gather_partials", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
@@ -297,6 +297,11 @@ class Context:
     def grand_product_values_dev(self, d_w, d_sigma, log_n, beta, gamma, d_vals, d_out):
         self._ck(self.lib.plk_grand_product_values_dev(self.h, _vp(d_w), _vp(d_sigma), C.c_uint32(log_n), _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))),
                                                        _vp(d_vals), _vp(d_out)))
+
+    def grand_product_dev_enqueue(self, d_w, d_sigma, log_n, beta, gamma, d_vals, d_out):
+        """grand_product_values_dev without the final wait (sync() before reading the outputs on the host)"""
+        self._ck(self.lib.plk_grand_product_dev_enqueue(self.h, _vp(d_w), _vp(d_sigma), C.c_uint32(log_n), _ptr(_fr(beta, (4,))), _ptr(_fr(gamma, (4,))),
+                                                        _vp(d_vals), _vp(d_out)))
 
     def ready(self, ticket) -> bool:
         r = C.c_int32(0)

@@ -163,12 +163,13 @@ void finish_points(const KZGProverKey& pk, const int32_t* tickets, int count, bo
 }
 // Order in which the independent MSMs of one round are enqueued (results do not depend on it).  One ordinary-sized MSM leads so
 // that the accumulation stream starts after a short sort; the MSMs of a handful of terms follow at once, so that their
-// reductions are long done when the round ends instead of queueing behind everybody else's on the reduction stream; two more
-// ordinary ones keep the accumulation stream busy while the long sort of the 4n-sized s_sigma runs; the rest longest first.
+// reductions are long done when the round ends instead of queueing behind everybody else's on the reduction stream; the rest
+// longest first: the 4n-sized s_sigma is then in the middle of the round (its sort runs on one of the two front streams while the
+// other feeds the accumulation), and the round ends with an ordinary MSM, whose reduction is the short one.
 void msm_order(int* order, int count, const uint64_t* len) {
     std::vector<int> tiny, rest;
     for (int i = 1; i < count; ++i) (len[i] <= 16 ? tiny : rest).push_back(i);
-    if (rest.size() > 2) std::stable_sort(rest.begin() + 2, rest.end(), [&](int x, int y) { return len[x] > len[y]; });
+    std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) { return len[x] > len[y]; });
     int k = 0;
     order[k++] = 0;
     for (int i : tiny) order[k++] = i;
@@ -275,18 +276,22 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     // transforms and pointwise pass (which need z but not its commitment) use the compute stream.
     // z_vals = domain.fft(&z_poly.coeffs) (:237) are the values the interpolation started from: kept in work[3], no transform.
     void* z_coeffs = in.work[2];
-    check(ctx, plk_grand_product_values_dev(ctx, in.witness_flat, in.sigma, log_n, beta.v, gamma.v, in.work[3], z_coeffs));
-    for (auto& r : blind[7]) r = rng();
-    int32_t z_ticket;
-    // From here to the end of round 3 compute work is detached: the quotient's kernels then run beside the sort of z instead of
-    // queueing behind it, where they would meet z's accumulation kernel and be starved until it drains.  (z's coefficients were
-    // written on the attached stream, so the commitment below still sees them.)
-    check(ctx, plk_compute_detach(ctx, 1));
+    // z on H (values only; the call returns when they are enqueued, the one inversion of the batch is done on the host inside it).
+    check(ctx, plk_grand_product_dev_enqueue(ctx, in.witness_flat, in.sigma, log_n, beta.v, gamma.v, in.work[3], nullptr));
     if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
         throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
-    // round 3's kernels first (:224-259): the host then enqueues the sorts of z and t while they run (measured: with the sort enqueued
-    // first the tail of the quotient's chain meets z's accumulation kernel and the round takes 0.1 ms longer)
+    // Round 3's kernels (:224-259) read the values, not the coefficients: they go to the detached stream now and run beside the
+    // interpolation and the sort of z.  They must be through before z's accumulation kernel starts: the transforms' workgroups
+    // (72 KB of LDS, four waves that start together) find no room beside its single-wave workgroups and would wait until it drains.
+    check(ctx, plk_compute_detach(ctx, 1));                                       // the detached stream waits for the values ...
+    check(ctx, plk_compute_detach(ctx, 2));
+    check(ctx, plk_copy_dev(ctx, z_coeffs, in.work[3], n * 32, n * 32));
+    check(ctx, plk_ntt_dev_enqueue(ctx, z_coeffs, log_n, 1, nullptr));           // z_poly = ifft(z) :208
+    check(ctx, plk_compute_detach(ctx, 3));                                       // ... but not for the interpolation
     check(ctx, plk_quotient_dev_enqueue(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4]));
+    // the commitments below are begun "detached": their sorts stay on the stream that carries z's coefficients
+    for (auto& r : blind[7]) r = rng();
+    int32_t z_ticket;
     check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
     // The quotient of this constraint system has degree < n before the division by Z_H, so it is either the zero polynomial or
     // the prover fails (:487).  Its commitment (three blinding terms, drawn here in the reference's rng order) is therefore
@@ -296,14 +301,14 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     check(ctx, plk_kzg_commit_begin(ctx, in.work[4], 0, &blind[8][0].v[0], &t_ticket));
     lap(1);
 
-    // ---- round 3: quotient t :224-259, on the detached compute stream.  The reductions of z and t are enqueued (plk_kzg_submit)
-    // after it, because they share that stream and wait for z's accumulation.
+    // ---- round 3: quotient t :224-259, on the detached compute stream.  The reductions of z and t (plk_kzg_submit) share that
+    // stream: enqueued behind the quotient's kernels, they wait for z's accumulation without holding anything up.
     uint64_t t_len = 0;
     // a failure below leaves both tickets open: the caller of prove_rounds gives them up
+    check(ctx, plk_kzg_submit(ctx));
     const int32_t rc_quotient = plk_quotient_dev_finish(ctx, &t_len);
     check(ctx, plk_compute_detach(ctx, 0));
     check(ctx, rc_quotient);
-    check(ctx, plk_kzg_submit(ctx));
     if (t_len != 0) {
         finish_point(pk, t_ticket);
         check(ctx, plk_kzg_commit_begin(ctx, in.work[4], t_len, &blind[8][0].v[0], &t_ticket));

@@ -149,6 +149,16 @@ def test_grand_product_values_and_ticket_batches(ctx, orc, srs):
     d_v, d_c = ctx.malloc(n * 32), ctx.malloc(n * 32)
     ctx.grand_product_values_dev(d_w, d_s, 6, beta, gamma, d_v, d_c)
     assert np.array_equal(ctx.download(d_v, (n, 4)), zv) and np.array_equal(ctx.download(d_c, (n, 4)), zc)
+    # the variant that does not wait: a commitment begun right after it is ordered behind the interpolation
+    d_v2, d_c2 = ctx.malloc(n * 32), ctx.malloc(n * 32)
+    ctx.grand_product_dev_enqueue(d_w, d_s, 6, beta, gamma, d_v2, d_c2)
+    z_blind = rand_fr(orc, 3, 949)
+    z_ticket = ctx.commit_begin(d_c2, n, z_blind)
+    ctx.sync()
+    assert np.array_equal(ctx.download(d_v2, (n, 4)), zv) and np.array_equal(ctx.download(d_c2, (n, 4)), zc)
+    got, inf = ctx.commit_end(z_ticket)
+    want_z = orc.kzg_commit(srs["g"], srs["gg"], zc, z_blind)
+    assert inf == want_z[1] and np.array_equal(got, want_z[0])
     polys = [rand_fr(orc, k, 900 + k) for k in (64, 0, 1, 4096, 100)]
     blinds = [rand_fr(orc, 3, 950 + i) for i in range(len(polys))]
     want = [orc.kzg_commit(srs["g"], srs["gg"], p, b) for p, b in zip(polys, blinds)]
@@ -160,7 +170,7 @@ def test_grand_product_values_and_ticket_batches(ctx, orc, srs):
         for i in (3, 0, 4, 1, 2):
             got, inf = ctx.commit_end(tickets[i])
             assert inf == want[i][1] and np.array_equal(got, want[i][0])
-    for d in dev + [d_w, d_s, d_v, d_c]:
+    for d in dev + [d_w, d_s, d_v, d_c, d_v2, d_c2]:
         ctx.free(d)
 
 
