@@ -85,6 +85,10 @@ static int32_t grow(plk_ctx* ctx, hipStream_t st, uint32_t** buf, uint64_t* cap,
 static int32_t sort_after_compute(plk_ctx* ctx, hipStream_t lane) {
     if (ctx->detached) return PLK_OK;   // the caller promised that this job's inputs do not come from the detached compute work
     if (lane == ctx->stream) return PLK_OK;
+    // The event also covers the divisions and sorts that earlier *_begin calls have put on the compute stream, which this job does
+    // not need.  Waiting for them all the same is the better schedule: with an event that marks the end of the compute work only,
+    // the two front streams run freely side by side, more sorting kernels share the chip with the accumulation kernels at a time,
+    // and a proof of 2^20 gates takes 0.5 ms longer (measured on one box: 31.5 against 31.0 ms).
     hipEvent_t ev;
     PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     PLK_HIP(hipEventRecord(ev, ctx->stream));

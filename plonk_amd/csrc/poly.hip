@@ -250,31 +250,13 @@ __device__ __forceinline__ fe perm_term(const fe& w_r, uint32_t idx, const fe& b
     norm(t);
     return t;
 }
-__global__ void __launch_bounds__(256) k_gp_terms(const uint32_t* __restrict__ wflat, const uint64_t* __restrict__ sigma, uint64_t n, W8 beta, W8 gamma,
-                                                  uint32_t* __restrict__ num, uint32_t* __restrict__ den, uint32_t* __restrict__ flag) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const fe beta2 = mul<FrP>(to_rp(fe_of(beta)), fe_const(FrP::R2)), gamma1 = to_rp(fe_of(gamma));
-    fe nu, de;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const uint64_t j = 3 * i + k;
-        uint64_t sj = sigma[j];
-        if (sj >= 3 * n) { atomicOr(flag, 2u); sj = 0; }
-        const fe tn = perm_term(ld_fe(wflat + 8 * j), (uint32_t)j, beta2, gamma1);
-        const fe td = perm_term(ld_fe(wflat + 8 * sj), (uint32_t)sj, beta2, gamma1);
-        nu = k == 0 ? tn : mul<FrP>(nu, tn);
-        de = k == 0 ? td : mul<FrP>(de, td);
-    }
-    // after the loop nu, de are products (bound 2) in the 2^261 form
-    st_lazy(num + 8 * i, nu);
-    st_lazy(den + 8 * i, de);
-}
-
 // Inclusive multiplicative scan of 2^261-form values, 2048 per block (8 per thread); reverse scans run from the top index down.
+// blockIdx.y selects one of several arrays scanned by the same launch (the grand product scans numerators and denominators together).
 constexpr int SCAN_PER_THREAD = 8;
 constexpr int SCAN_BLOCK = 256 * SCAN_PER_THREAD;
-__global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data, uint64_t n, int reverse, uint32_t* __restrict__ block_tot) {
+// element(i) yields the value at scan position i < n; the inclusive prefix of position i goes to out + 8 * (reverse ? n - 1 - i : i)
+template <typename Element>
+__device__ __forceinline__ void scan_block(Element element, uint32_t* __restrict__ out, uint64_t n, int reverse, uint32_t* __restrict__ block_tot) {
     __shared__ uint32_t wave_tot[4][9];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
@@ -283,7 +265,7 @@ __global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data,
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; ++k) {
         const uint64_t i = base + k;
-        if (i < n) run = mul<FrP>(run, ld_fe(data + 8 * (reverse ? n - 1 - i : i)));
+        if (i < n) run = mul<FrP>(run, element(i));
         p[k] = run;
     }
     fe incl = run;
@@ -313,37 +295,82 @@ __global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data,
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; ++k) {
         const uint64_t i = base + k;
-        if (i < n) st_lazy(data + 8 * (reverse ? n - 1 - i : i), mul<FrP>(excl, p[k]));
+        if (i < n) st_lazy(out + 8 * (reverse ? n - 1 - i : i), mul<FrP>(excl, p[k]));
     }
     if (threadIdx.x == 255) st_lazy(block_tot + 8ull * blockIdx.x, mul<FrP>(excl, p[SCAN_PER_THREAD - 1]));
 }
-__global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ data, uint64_t n, int reverse, const uint32_t* __restrict__ block_incl) {
+__global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data, uint64_t data_stride, uint64_t n, int reverse, uint32_t* __restrict__ block_tot,
+                                                    uint64_t tot_stride) {
+    uint32_t* d = data + blockIdx.y * data_stride;
+    scan_block([&](uint64_t i) { return ld_fe(d + 8 * (reverse ? n - 1 - i : i)); }, d, n, reverse, block_tot + blockIdx.y * tot_stride);
+}
+__global__ void __launch_bounds__(256) k_scan_apply(uint32_t* __restrict__ data, uint64_t data_stride, uint64_t n, int reverse, const uint32_t* __restrict__ block_incl,
+                                                    uint64_t tot_stride) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint64_t b = i / SCAN_BLOCK;
     if (b == 0) return;
-    uint32_t* p = data + 8 * (reverse ? n - 1 - i : i);
-    st_lazy(p, mul<FrP>(ld_fe(block_incl + 8 * (b - 1)), ld_fe(p)));
+    uint32_t* p = data + blockIdx.y * data_stride + 8 * (reverse ? n - 1 - i : i);
+    st_lazy(p, mul<FrP>(ld_fe(block_incl + blockIdx.y * tot_stride + 8 * (b - 1)), ld_fe(p)));
 }
-// in-place inclusive scan; work must hold the block totals of every level (<= n/1024 elements in all)
-static int32_t scan_mul(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint64_t n, bool reverse, uint32_t* work) {
+// in-place inclusive scans of `arrays` arrays of n elements, data_stride words apart; work must hold the block totals of every
+// level (arrays * (n / 2048 + n / 2048^2 + ...) elements, rounded up per level)
+static int32_t scan_mul(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint64_t data_stride, uint32_t arrays, uint64_t n, bool reverse, uint32_t* work) {
     const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb), dim3(256), 0, st, data, n, reverse ? 1 : 0, work);
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb, arrays), dim3(256), 0, st, data, data_stride, n, reverse ? 1 : 0, work, 8 * nb);
     if (nb > 1) {
-        PLK_TRY(scan_mul(ctx, st, work, nb, false, work + 8 * nb));
-        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, n, reverse ? 1 : 0, work);
+        PLK_TRY(scan_mul(ctx, st, work, 8 * nb, arrays, nb, false, work + (size_t)arrays * 8 * nb));
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)((n + 255) / 256), arrays), dim3(256), 0, st, data, data_stride, n, reverse ? 1 : 0, work, 8 * nb);
     }
     PLK_HIP(hipGetLastError());
     return PLK_OK;
 }
-// z[0] = 1, z[i] = N_{i-1} * S_i / D for 0 < i < n, with N the prefix products of the numerators, S the suffix
-// products of the denominators, dinv = D^-1 * 2^256.
-__global__ void __launch_bounds__(256) k_gp_finish(const uint32_t* __restrict__ num_pre, const uint32_t* __restrict__ den_suf, uint64_t n, W8 dinv,
-                                                   uint32_t* __restrict__ z) {
+
+// Grand product, first pass.  blockIdx.y = 0: numerators of the rows in index order; 1: denominators from the top row down.  The
+// terms are computed where they are needed (three per row) and go straight into the block's scan: prefix products inside the block
+// -> num / den (indexed by row), the block's product -> tot.
+__global__ void __launch_bounds__(256) k_gp_local(const uint32_t* __restrict__ wflat, const uint64_t* __restrict__ sigma, uint64_t n, W8 beta, W8 gamma,
+                                                  uint32_t* __restrict__ num, uint32_t* __restrict__ den, uint32_t* __restrict__ tot, uint64_t tot_stride,
+                                                  uint32_t* __restrict__ flag) {
+    const fe beta2 = mul<FrP>(to_rp(fe_of(beta)), fe_const(FrP::R2)), gamma1 = to_rp(fe_of(gamma));
+    if (blockIdx.y == 0) {
+        scan_block([&](uint64_t i) {
+            fe nu;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint64_t j = 3 * i + k;
+                const fe tn = perm_term(ld_fe(wflat + 8 * j), (uint32_t)j, beta2, gamma1);
+                nu = k == 0 ? tn : mul<FrP>(nu, tn);
+            }
+            return nu;
+        }, num, n, 0, tot);
+    } else {
+        scan_block([&](uint64_t i) {
+            const uint64_t row = n - 1 - i;
+            fe de;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                uint64_t sj = sigma[3 * row + k];
+                if (sj >= 3 * n) { atomicOr(flag, 2u); sj = 0; }
+                const fe td = perm_term(ld_fe(wflat + 8 * sj), (uint32_t)sj, beta2, gamma1);
+                de = k == 0 ? td : mul<FrP>(de, td);
+            }
+            return de;
+        }, den, n, 1, tot + tot_stride);
+    }
+}
+// z[0] = 1, z[i] = N_{i-1} * S_i / D for 0 < i < n, with N the prefix products of the numerators, S the suffix products of the
+// denominators (each the block-local product from k_gp_local times the scanned product of the blocks before), dinv = D^-1 * 2^256.
+__global__ void __launch_bounds__(256) k_gp_finish(const uint32_t* __restrict__ num_loc, const uint32_t* __restrict__ den_loc, const uint32_t* __restrict__ tot_incl,
+                                                   uint64_t tot_stride, uint64_t n, W8 dinv, uint32_t* __restrict__ z) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     if (i == 0) { st_fe<FrP>(z, mul<FrP>(fe_const(FrP::ONE), fe_const(FrP::TO_R))); return; }
-    st_fe<FrP>(z + 8 * i, mul<FrP>(mul<FrP>(ld_fe(num_pre + 8 * (i - 1)), ld_fe(den_suf + 8 * i)), fe_of(dinv)));
+    const uint64_t bn = (i - 1) / SCAN_BLOCK, bd = (n - 1 - i) / SCAN_BLOCK;     // scan blocks of N_{i-1} and of S_i
+    fe nu = ld_fe(num_loc + 8 * (i - 1)), de = ld_fe(den_loc + 8 * i);
+    if (bn) nu = mul<FrP>(ld_fe(tot_incl + 8 * (bn - 1)), nu);
+    if (bd) de = mul<FrP>(ld_fe(tot_incl + tot_stride + 8 * (bd - 1)), de);
+    st_fe<FrP>(z + 8 * i, mul<FrP>(mul<FrP>(nu, de), fe_of(dinv)));
 }
 
 // ------------------------------------------------------------------------------------------ quotient numerator on H
@@ -622,14 +649,14 @@ static int32_t grand_product(plk_ctx* ctx, const void* witness_flat_dev, const v
     uint32_t *num = ctx->scratch, *den = num + 8 * n, *work = den + 8 * n;
     PLK_HIP(hipMemsetAsync(ctx->flag_dev, 0, 4, st));
     prof_begin(ctx, st, "pointwise");
-    hipLaunchKernelGGL(k_gp_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)witness_flat_dev, (const uint64_t*)sigma_dev, n,
-                       w8_of(beta), w8_of(gamma), num, den, ctx->flag_dev);
-    PLK_TRY(scan_mul(ctx, st, num, n, false, work));
-    PLK_TRY(scan_mul(ctx, st, den, n, true, work));
+    const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK, tot_stride = 8 * nb;    // work: block products of the numerators, of the denominators, deeper levels
+    hipLaunchKernelGGL(k_gp_local, dim3((unsigned)nb, 2), dim3(256), 0, st, (const uint32_t*)witness_flat_dev, (const uint64_t*)sigma_dev, n, w8_of(beta), w8_of(gamma), num, den,
+                       work, tot_stride, ctx->flag_dev);
+    if (nb > 1) PLK_TRY(scan_mul(ctx, st, work, tot_stride, 2, nb, false, work + 2 * tot_stride));
     prof_end(ctx, st);
-    // one inversion of the full denominator product on the host
+    // one inversion of the full denominator product (the last scanned block product) on the host
     uint64_t dtot[4];
-    PLK_HIP(hipMemcpyAsync(dtot, den, 32, hipMemcpyDeviceToHost, st));
+    PLK_HIP(hipMemcpyAsync(dtot, work + tot_stride + 8 * (nb - 1), 32, hipMemcpyDeviceToHost, st));
     uint32_t flag;
     PLK_TRY(read_flag(ctx, &flag));
     if (flag & 2u) { ctx->err = "sigma entry out of range"; return PLK_ERR_INDEX_OUT_OF_RANGE; }
@@ -639,7 +666,8 @@ static int32_t grand_product(plk_ctx* ctx, const void* witness_flat_dev, const v
     if (host::is_zero(d)) { ctx->err = "grand product: denominator is zero"; return PLK_ERR_INVERSE_OF_ZERO; }
     const host::el dinv = host::mul(host::FR, host::inv(host::FR, d), host::from_u64(host::FR, 32));
     prof_begin(ctx, st, "pointwise");
-    hipLaunchKernelGGL(k_gp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, num, den, n, w8_of(dinv), (uint32_t*)(z_coeffs_out_dev ? z_coeffs_out_dev : z_vals_out_dev));
+    hipLaunchKernelGGL(k_gp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, num, den, work, tot_stride, n, w8_of(dinv),
+                       (uint32_t*)(z_coeffs_out_dev ? z_coeffs_out_dev : z_vals_out_dev));
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
     if (!z_coeffs_out_dev) return PLK_OK;

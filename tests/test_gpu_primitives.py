@@ -137,6 +137,28 @@ def test_grand_product_and_quotient(ctx, orc, log_n):
     assert orc.quotient(a, b, bad, qa, qm, zv, sigma, beta, gamma) == 1
 
 
+@pytest.mark.parametrize("log_n", [11, 12, 15])
+def test_grand_product_of_random_rows(ctx, orc, log_n):
+    """One, two and sixteen scan blocks (2048 rows each): any rows and any permutation have a grand product, no circuit needed.
+    Values and coefficients against the oracle, through the waiting call and through the values-only enqueue variant."""
+    n = 1 << log_n
+    rng = np.random.default_rng(300 + log_n)
+    w = rand_fr(orc, 3 * 257, 40 + log_n)[rng.integers(0, 3 * 257, 3 * n)]
+    sigma = rng.permutation(3 * n).astype(np.uint64)
+    beta, gamma = rand_fr(orc, 2, 60 + log_n)
+    zv, zc = orc.grand_product(w, sigma, beta, gamma)
+    d_w, d_s = ctx.upload(w), ctx.upload(sigma)
+    d_v, d_c = ctx.malloc(n * 32), ctx.malloc(n * 32)
+    ctx.grand_product_values_dev(d_w, d_s, log_n, beta, gamma, d_v, d_c)
+    assert np.array_equal(ctx.download(d_v, (n, 4)), zv) and np.array_equal(ctx.download(d_c, (n, 4)), zc)
+    ctx.upload_into(d_v, np.zeros((n, 4), np.uint64))
+    ctx.grand_product_dev_enqueue(d_w, d_s, log_n, beta, gamma, d_v, None)
+    ctx.sync()
+    assert np.array_equal(ctx.download(d_v, (n, 4)), zv)
+    for d in (d_w, d_s, d_v, d_c):
+        ctx.free(d)
+
+
 def test_grand_product_values_and_ticket_batches(ctx, orc, srs):
     """plk_grand_product_values_dev hands out z on H beside the coefficients; tickets of one batch may be ended in any order,
     with or without plk_kzg_submit."""
@@ -171,6 +193,26 @@ def test_grand_product_values_and_ticket_batches(ctx, orc, srs):
             got, inf = ctx.commit_end(tickets[i])
             assert inf == want[i][1] and np.array_equal(got, want[i][0])
     for d in dev + [d_w, d_s, d_v, d_c, d_v2, d_c2]:
+        ctx.free(d)
+
+
+def test_commitments_see_compute_work_enqueued_between_begins(ctx, orc, srs):
+    """Jobs of one batch alternate between two front streams, only one of which carries the compute work: a transform enqueued
+    between two *_begin calls must be finished before the commitment that reads its output starts, whichever stream that
+    commitment's sort lands on."""
+    log_n = 11
+    polys = [rand_fr(orc, 1 << log_n, 700 + i) for i in range(5)]
+    blinds = [rand_fr(orc, 3, 720 + i) for i in range(5)]
+    devs = [ctx.upload(p) for p in polys]
+    tickets = []
+    for d, b in zip(devs, blinds):
+        ctx.ntt_dev_enqueue(d, log_n)
+        tickets.append(ctx.commit_begin(d, 1 << log_n, b))
+    for t, p, b in zip(tickets, polys, blinds):
+        got, inf = ctx.commit_end(t)
+        want = orc.kzg_commit(srs["g"], srs["gg"], orc.ntt(p), b)
+        assert inf == want[1] and np.array_equal(got, want[0])
+    for d in devs:
         ctx.free(d)
 
 

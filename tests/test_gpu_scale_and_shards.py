@@ -134,6 +134,29 @@ def _random_residues(count, seed):
     return raw
 
 
+def test_grand_product_2p23_three_scan_levels(orc):
+    """2^23 rows = 4096 scan blocks: the block products themselves need two blocks and a third level.  Random rows and a random
+    permutation; z on H against the oracle."""
+    log_n = 23
+    n = 1 << log_n
+    rng = np.random.default_rng(23)
+    base = orc.fr_from_ints([int.from_bytes(rng.bytes(40), "little") for _ in range(4099)])
+    w = base[rng.integers(0, len(base), 3 * n)]
+    sigma = rng.permutation(3 * n).astype(np.uint64)
+    beta, gamma = base[0], base[1]
+    zv, _ = orc.grand_product(w, sigma, beta, gamma)
+    from plonk_amd.hip import Context
+    ctx = Context(0)
+    d_w, d_s, d_v = ctx.upload(w), ctx.upload(sigma), ctx.malloc(n * 32)
+    ctx.grand_product_dev_enqueue(d_w, d_s, log_n, beta, gamma, d_v, None)
+    ctx.sync()
+    got = ctx.download(d_v, (n, 4))
+    for d in (d_w, d_s, d_v):
+        ctx.free(d)
+    ctx.close()
+    assert np.array_equal(got, zv)
+
+
 def test_stress_msm_2p24_through_the_trapdoor(orc):
     """BASELINE configs[4], MSM half: 2^24 SRS points [tau^i] G with uniformly random scalars (seed 2).  With the trapdoor the
     answer is (sum_i s_i tau^i) G: one Horner pass on the CPU instead of a 2^24-point MSM."""
