@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint32_t* __rest
 constexpr int NTT8_TILE = 2048;
 constexpr int NTT8_THREADS = 256;
 constexpr int NTT8_MAX_LOG_R = 8;   // 2048 * 36 B of data + 128 * 36 B of twiddles: two workgroups fit the 160 KB of a CU
+constexpr int NTT8_LDS_BYTES = (NTT8_TILE * 9 + (1 << (NTT8_MAX_LOG_R - 1)) * 9) * 4;
 
 struct Ntt8Pass {
     uint32_t log_n, log_r, log_ns, log_t;
@@ -246,8 +247,12 @@ template <bool IN_F, bool OUT_F, bool TW_T>
 __global__ void __launch_bounds__(NTT8_THREADS) k_ntt_pass8(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ W, Ntt8Pass a,
                                                             NttScale scale /* x*2^256 words */, const uint32_t* __restrict__ in_factors,
                                                             const uint32_t* __restrict__ out_factors) {
-    __shared__ uint32_t lds[NTT8_TILE * 9];
-    __shared__ uint32_t tw[(1 << (NTT8_MAX_LOG_R - 1)) * 9];
+    // LDS handed over at launch: told the size, the compiler sizes the register allocation for the two workgroups per CU that
+    // 78 KB permit (169 registers allocated for 157 used), and the kernel's waves then do not fit into the 160 registers that two
+    // accumulation waves leave free on a SIMD.
+    extern __shared__ uint32_t ntt8_lds[];
+    uint32_t* lds = ntt8_lds;
+    uint32_t* tw = ntt8_lds + NTT8_TILE * 9;
     const uint32_t log_r = a.log_r, log_t = a.log_t, T = 1u << log_t;
     for (uint32_t e = threadIdx.x; e < (1u << (log_r - 1)); e += NTT8_THREADS) {
         fe w = twiddle_operand(W, e << (a.log_n - log_r), a.log_n, a.inverse);
@@ -562,18 +567,29 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
                 left -= q;
             }
             const dim3 grid((uint32_t)(n / NTT8_TILE)), block(NTT8_THREADS);
+            static const bool lds_allowed = [] {   // more than the 64 KB a kernel may take without asking
+                bool ok = true;
+                auto allow = [&](const void* f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NTT8_LDS_BYTES) == hipSuccess; };
+                allow(reinterpret_cast<const void*>(k_ntt_pass8<false, true, false>));
+                allow(reinterpret_cast<const void*>(k_ntt_pass8<false, false, false>));
+                allow(reinterpret_cast<const void*>(k_ntt_pass8<true, false, true>));
+                allow(reinterpret_cast<const void*>(k_ntt_pass8<false, false, true>));
+                allow(reinterpret_cast<const void*>(k_ntt_pass8<true, false, false>));
+                return ok;
+            }();
+            if (!lds_allowed) { ctx->err = "k_ntt_pass8: 78 KB of LDS refused"; return PLK_ERR_HIP; }
             const uint32_t* tw_next = nullptr;
             if (!last && log_n <= NTT_TABLE_MAX_LOG_N) PLK_TRY(pass_twiddles(ctx, st, W, log_n, inverse, p, lr[p + 1], lns[p] + lr[p], &tw_next));
             const bool in_f = factors && p == 0 && !inverse;
             if (last) {
-                if (factors && inverse) hipLaunchKernelGGL((k_ntt_pass8<false, true, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, factors);
-                else hipLaunchKernelGGL((k_ntt_pass8<false, false, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, nullptr);
+                if (factors && inverse) hipLaunchKernelGGL((k_ntt_pass8<false, true, false>), grid, block, NTT8_LDS_BYTES, st, src, dst, W, a, ninv, nullptr, factors);
+                else hipLaunchKernelGGL((k_ntt_pass8<false, false, false>), grid, block, NTT8_LDS_BYTES, st, src, dst, W, a, ninv, nullptr, nullptr);
             } else if (tw_next) {
-                if (in_f) hipLaunchKernelGGL((k_ntt_pass8<true, false, true>), grid, block, 0, st, src, dst, W, a, ninv, factors, tw_next);
-                else hipLaunchKernelGGL((k_ntt_pass8<false, false, true>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, tw_next);
+                if (in_f) hipLaunchKernelGGL((k_ntt_pass8<true, false, true>), grid, block, NTT8_LDS_BYTES, st, src, dst, W, a, ninv, factors, tw_next);
+                else hipLaunchKernelGGL((k_ntt_pass8<false, false, true>), grid, block, NTT8_LDS_BYTES, st, src, dst, W, a, ninv, nullptr, tw_next);
             } else {
-                if (in_f) hipLaunchKernelGGL((k_ntt_pass8<true, false, false>), grid, block, 0, st, src, dst, W, a, ninv, factors, nullptr);
-                else hipLaunchKernelGGL((k_ntt_pass8<false, false, false>), grid, block, 0, st, src, dst, W, a, ninv, nullptr, nullptr);
+                if (in_f) hipLaunchKernelGGL((k_ntt_pass8<true, false, false>), grid, block, NTT8_LDS_BYTES, st, src, dst, W, a, ninv, factors, nullptr);
+                else hipLaunchKernelGGL((k_ntt_pass8<false, false, false>), grid, block, NTT8_LDS_BYTES, st, src, dst, W, a, ninv, nullptr, nullptr);
             }
         }
         src = dst;

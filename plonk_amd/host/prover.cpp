@@ -246,9 +246,9 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
         // Selector values on H for round 3 (domain.fft(&q_add.coeffs), :232-233) depend on no challenge.  They are enqueued here on the
         // detached compute stream, which also carries the reductions just submitted: they start when the last reduction of the round
         // has finished and run while the host finishes the commitments and the transcript, and beside the grand product, whose kernels
-        // leave most of the chip idle.  (Enqueued behind the sorts instead, their workgroups - 72 KB of LDS, 157 registers, four waves
-        // that must start together - found no room beside the single-wave workgroups of the accumulation kernels until the round's
-        // last kernel drained, and then ran on the critical path.)
+        // leave most of the chip idle.  (Enqueued behind the sorts instead, they ran on the critical path: measured when the
+        // transform kernel was still allocated 176 registers per wave, 16 more than two accumulation waves leave free on a SIMD, so
+        // that its workgroups found no room until the round's last accumulation kernel drained.)
         if (in.len[0] >= n && in.len[1] >= n && in.len[2] >= n) {
             check(ctx, plk_compute_detach(ctx, 1));
             check(ctx, plk_copy_dev(ctx, in.work[0], in.poly[3], in.len[3] * 32, n * 32));
@@ -281,8 +281,7 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     if (in.len[0] < n || in.len[1] < n || in.len[2] < n)    // :229-231 -> src/circuit.rs:356-358 index past the end of a trimmed column
         throw Error(PLK_ERR_INDEX_OUT_OF_RANGE, "index out of bounds: a wire polynomial has fewer than domain.size() coefficients");
     // Round 3's kernels (:224-259) read the values, not the coefficients: they go to the detached stream now and run beside the
-    // interpolation and the sort of z.  They must be through before z's accumulation kernel starts: the transforms' workgroups
-    // (72 KB of LDS, four waves that start together) find no room beside its single-wave workgroups and would wait until it drains.
+    // interpolation and the sort of z, and are through before z's accumulation kernel starts (beside it every kernel is slower).
     check(ctx, plk_compute_detach(ctx, 1));                                       // the detached stream waits for the values ...
     check(ctx, plk_compute_detach(ctx, 2));
     check(ctx, plk_copy_dev(ctx, z_coeffs, in.work[3], n * 32, n * 32));
