@@ -352,15 +352,29 @@ k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restric
     }
     uint32_t next = bucket_start[b + 1];
     xyzz acc = xyzz_inf();
-    uint32_t enc0 = entries[e];
     uint32_t enc1 = e + 1 < e_end ? entries[e + 1] : 0;
-    uint32_t wx[8], wy[8];
+    aff q;   // the point of entry e, unpacked and with its sign applied
     {
+        const uint32_t enc0 = entries[e];
+        uint32_t wx[8], wy[8];
         const uint32_t* p = tables + (size_t)(enc0 & 0x7fffffffu) * 16;
         load8(p, wx);
         load8(p + 8, wy);
+        q.x = unpack(wx);
+        q.y = unpack(wy);
+        if (enc0 >> 31) q.y = fq_neg_y(q.y);
     }
+    // Order inside an iteration: (1) the bucket change, whose loads are waited for at once, while nothing else is in flight;
+    // (2) the loads of the next point; (3) the addition, which touches no loaded register; (4) the next point is unpacked, and only
+    // here the wave waits for (2).  With the loaded words consumed at the top of the iteration the compiler put a wait for ALL
+    // outstanding loads there (it cannot count the loads issued under a divergent condition), and the wave sat out the full latency
+    // of the gather it had just issued, in every iteration.
     while (true) {
+        if (e == next) {   // the run leaves bucket b here
+            st_xyzz(flushed + (size_t)b * XYZZ_WORDS, acc);
+            acc = xyzz_inf();
+            do { ++b; next = bucket_start[b + 1]; } while (next <= e);
+        }
         const bool more = e + 1 < e_end;
         uint32_t nx[8], ny[8], enc2 = 0;
         if (more) {
@@ -369,20 +383,12 @@ k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restric
             load8(p + 8, ny);
             if (e + 2 < e_end) enc2 = entries[e + 2];
         }
-        if (e == next) {   // the run leaves bucket b here
-            st_xyzz(flushed + (size_t)b * XYZZ_WORDS, acc);
-            acc = xyzz_inf();
-            do { ++b; next = bucket_start[b + 1]; } while (next <= e);
-        }
-        aff q;
-        q.x = unpack(wx);
-        q.y = unpack(wy);
-        if (enc0 >> 31) q.y = fq_neg_y(q.y);
         xyzz_madd(acc, q);
         if (!more) break;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wx[i] = nx[i]; wy[i] = ny[i]; }
-        enc0 = enc1; enc1 = enc2; ++e;
+        q.x = unpack(nx);
+        q.y = unpack(ny);
+        if (enc1 >> 31) q.y = fq_neg_y(q.y);
+        enc1 = enc2; ++e;
     }
     uint32_t* dst = tails + lane;
 #pragma unroll
