@@ -17,7 +17,6 @@ namespace plk {
 constexpr int MSM_C = 16;
 constexpr int MSM_WINDOWS = 16;
 constexpr int MSM_BUCKETS = 1 << 15;
-constexpr int MSM_MAX_BLOCKS = 256;     // blocks of the counting / scatter kernels (rows of the count matrix)
 constexpr int MSM_SLOTS = 10;           // MSMs in flight (a round of the prover enqueues up to nine at once)
 constexpr int MSM_MARGINALS = 56;       // 16 + 16 + 16 + 8 partial sums handed to the host
 constexpr int XYZZ_WORDS = 36;          // unnormalised point in device scratch: 4 coordinates x 9 limbs
@@ -51,8 +50,8 @@ struct PendingEvent {
 struct MsmSlot {
     bool ready = false;
     hipEvent_t sorted = nullptr, accumulated = nullptr, done = nullptr;   // stage hand-offs between the three MSM streams
-    uint32_t* counts = nullptr;        // [MSM_MAX_BLOCKS][MSM_BUCKETS]
-    uint32_t* totals = nullptr;        // [MSM_BUCKETS]
+    uint32_t* counts = nullptr;        // [workgroups of the sort][partitions]
+    uint32_t* totals = nullptr;        // [MSM_BUCKETS] (the sort keeps its partition starts here)
     uint32_t* bucket_start = nullptr;  // [MSM_BUCKETS + 1]
     uint32_t* entries = nullptr;       // sorted (table index | sign << 31)
     uint64_t entries_cap = 0;

@@ -5,11 +5,10 @@
 // single set of 2^15 buckets:  sum_i s_i P_i = sum_k k * B_k,  B_k = sum of +-T[j][i] over all (i, j)
 // whose signed 16-bit digit has magnitude k.
 //
-// Pipeline of one MSM (sort on the front stream, accumulation and reduction on streams of their own, several MSMs in flight):
-//   digits    : signed 16-bit digits of every scalar, as 16 two-byte codes                       -> digits[scalar][16]
-//   count     : per workgroup (a chunk of scalars x half of the buckets) histogram in LDS (64 KiB) -> counts[chunk][bucket]
-//   totals / scan / offsets : bucket sizes, bucket starts, per-(chunk, bucket) write cursors
-//   scatter   : second pass over the digit codes, LDS cursors hand out slots      -> entries sorted by bucket
+// Pipeline of one MSM (sort on a front stream, accumulation and reduction on streams of their own, several MSMs in flight):
+//   digits + count : signed 16-bit digits of every scalar as 16 two-byte codes, histogram of 256 partitions per workgroup
+//   partition      : every workgroup appends its 8-byte records to its own piece of each partition (upper 8 bucket bits)
+//   buckets        : one workgroup per partition spreads the records over the partition's 128 buckets -> entries sorted by bucket
 //   accumulate: every lane adds one run of consecutive sorted entries (mixed XYZZ additions); sums of runs that end inside a
 //               bucket are joined by the fold kernel                              -> bucket_sums
 //   marginals : sum_k k B_k is linear in the bits of k; the bucket index is cut into 4 bit-fields and the
@@ -26,8 +25,8 @@ namespace plk {
 
 // ------------------------------------------------------------------------------------------ scalars -> digits
 // scalar in memory: x * 2^256, canonical.  Returns 16 signed digits d_j in [-2^15+1, 2^15] with x = sum d_j 2^(16 j).
-__device__ __forceinline__ void scalar_digits(const uint32_t* sp, int32_t* d) {
-    const fe s = reduce<FrP>(mul<FrP>(ld_fe(sp), fe_const(FrP::RAW32)));
+__device__ __forceinline__ void scalar_digits(const uint32_t* sw, int32_t* d) {   // sw: the scalar's eight words, already loaded
+    const fe s = reduce<FrP>(mul<FrP>(unpack(sw), fe_const(FrP::RAW32)));
     uint32_t w[8];
     pack(s, w);
     uint32_t carry = 0;
@@ -55,149 +54,44 @@ __device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint3
 }
 
 constexpr int SORT_THREADS = 256;   // four waves per block: a block fits beside the accumulation kernel's waves on a busy CU
-// Digits of every scalar, once per MSM: sixteen 16-bit codes per scalar, bit 15 = sign, bits 0-14 = bucket (|d| - 1); 0xffff = no entry
-// (d = 0; the code would otherwise mean d = -2^15, which the signed recoding never produces).  The counting and the scattering pass
-// read these 32 bytes per scalar instead of converting the scalar out of Montgomery form again.
+// Digit of one window as a 16-bit code: bit 15 = sign, bits 0-14 = bucket (|d| - 1); 0xffff = no entry (d = 0; the code would
+// otherwise mean d = -2^15, which the signed recoding never produces).
 constexpr uint32_t DIGIT_NONE = 0xffffu;
-__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs segs, uint32_t* __restrict__ digits) {
-    PLK_SIDE_PRIO();
-    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= segs.total) return;
-    uint32_t ti;
-    const uint32_t* sp = seg_scalar(segs, idx, &ti);
-    int32_t d[MSM_WINDOWS];
-    scalar_digits(sp, d);
-    uint32_t w[MSM_WINDOWS / 2];
-#pragma unroll
-    for (int j = 0; j < MSM_WINDOWS; j += 2) {
-        const uint32_t lo = d[j] == 0 ? DIGIT_NONE : ((d[j] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1));
-        const uint32_t hi = d[j + 1] == 0 ? DIGIT_NONE : ((d[j + 1] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j + 1] < 0 ? -d[j + 1] : d[j + 1]) - 1));
-        w[j / 2] = lo | (hi << 16);
-    }
-    store8(digits + 8ull * idx, w);
-}
-// Each workgroup takes a chunk of scalars and one of 2^log_split bucket ranges: the histogram in LDS covers that range only, and the
-// pieces a workgroup later writes per bucket are 2^log_split times longer than they would be with one workgroup per chunk.
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const uint32_t* __restrict__ digits, uint32_t total, uint32_t chunk, uint32_t* __restrict__ counts,
-                                                            uint32_t log_split) {
-    PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
-    extern __shared__ uint32_t hist[];   // counters of this workgroup's bucket range; dynamic so that the compiler does not pad the register allocation to the LDS-limited occupancy
-    const uint32_t nb = MSM_BUCKETS >> log_split, range = blockIdx.y, range_shift = 15 - log_split;
-    for (uint32_t i = threadIdx.x; i < nb; i += SORT_THREADS) hist[i] = 0;
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * chunk;
-    const uint32_t hi = min(lo + chunk, total);
-    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
-        uint32_t w[8];
-        load8(digits + 8ull * idx, w);
-#pragma unroll
-        for (int j = 0; j < MSM_WINDOWS; ++j) {
-            const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            const uint32_t b = code & 0x7fffu;
-            if (code != DIGIT_NONE && (b >> range_shift) == range) atomicAdd(&hist[b & (nb - 1)], 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t* row = counts + (size_t)blockIdx.x * MSM_BUCKETS + (size_t)range * nb;
-    for (uint32_t i = threadIdx.x; i < nb; i += SORT_THREADS) row[i] = hist[i];
-}
-
-__global__ void __launch_bounds__(256) k_msm_totals(const uint32_t* __restrict__ counts, uint32_t nblocks, uint32_t* __restrict__ totals) {
-    PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    uint32_t s = 0;
-    for (uint32_t k = 0; k < nblocks; ++k) s += counts[(size_t)k * MSM_BUCKETS + b];
-    totals[b] = s;
-}
-// exclusive scan of MSM_BUCKETS totals by one block of 256 threads (128 consecutive buckets per thread; a four-wave block
-// can be placed on a CU that is busy with accumulation waves, a sixteen-wave block cannot)
-__global__ void __launch_bounds__(256) k_msm_scan(const uint32_t* __restrict__ totals, uint32_t* __restrict__ bucket_start) {
-    PLK_SIDE_PRIO();
-    __shared__ uint32_t wave_sum[4];
-    constexpr int PER = MSM_BUCKETS / 256;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint4* src = reinterpret_cast<const uint4*>(totals + t * PER);
-    uint32_t s = 0;
-    for (int i = 0; i < PER / 4; ++i) { const uint4 v = src[i]; s += v.x + v.y + v.z + v.w; }
-    uint32_t incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t x = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += x; }
-    if (lane == 63) wave_sum[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - s;
-    for (uint32_t k = 0; k < wave; ++k) run += wave_sum[k];
-    uint4* dst = reinterpret_cast<uint4*>(bucket_start + t * PER);
-    for (int i = 0; i < PER / 4; ++i) {
-        const uint4 v = src[i];
-        uint4 o;
-        o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run; run += v.w;
-        dst[i] = o;
-    }
-    if (t == 255) bucket_start[MSM_BUCKETS] = run;
-}
-__global__ void __launch_bounds__(256) k_msm_offsets(uint32_t* __restrict__ counts, uint32_t nblocks, const uint32_t* __restrict__ bucket_start) {
-    PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    uint32_t run = bucket_start[b];
-    for (uint32_t k = 0; k < nblocks; ++k) {
-        const size_t at = (size_t)k * MSM_BUCKETS + b;
-        const uint32_t c = counts[at];
-        counts[at] = run;
-        run += c;
-    }
-}
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(MsmSegs segs, const uint32_t* __restrict__ digits, uint32_t chunk, const uint32_t* __restrict__ offsets,
-                                                              uint32_t table_stride, uint32_t* __restrict__ entries, uint32_t log_split) {
-    PLK_SIDE_PRIO();
-    extern __shared__ uint32_t cursor[];   // write cursors of this workgroup's bucket range (dynamic LDS, see k_msm_count)
-    const uint32_t nb = MSM_BUCKETS >> log_split, range = blockIdx.y, range_shift = 15 - log_split;
-    const uint32_t* row = offsets + (size_t)blockIdx.x * MSM_BUCKETS + (size_t)range * nb;
-    for (uint32_t i = threadIdx.x; i < nb; i += SORT_THREADS) cursor[i] = row[i];
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * chunk;
-    const uint32_t hi = min(lo + chunk, segs.total);
-    for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
-        uint32_t ti;
-        (void)seg_scalar(segs, idx, &ti);      // only the table index of scalar idx is needed here
-        uint32_t w[8];
-        load8(digits + 8ull * idx, w);
-#pragma unroll
-        for (int j = 0; j < MSM_WINDOWS; ++j) {
-            const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            const uint32_t b = code & 0x7fffu;
-            if (code == DIGIT_NONE || (b >> range_shift) != range) continue;
-            const uint32_t slot = atomicAdd(&cursor[b & (nb - 1)], 1u);
-            entries[slot] = ((code & 0x8000u) << 16) | ((uint32_t)j * table_stride + ti);
-        }
-    }
+__device__ __forceinline__ uint32_t digit_code(int32_t d) {
+    return d == 0 ? DIGIT_NONE : ((d < 0 ? 0x8000u : 0u) | (uint32_t)((d < 0 ? -d : d) - 1));
 }
 
 // ------------------------------------------------------------------------------------------ two-level sort
-// The one-level scatter above hands every (chunk, bucket) pair its own few slots, so each 4-byte store lands in a line that no
-// other store of the same workgroup completes soon: the line leaves the L2 with four valid bytes and memory sees one partial write
-// per entry.  Here the entries first go to SORT_PARTS = 256 partitions by the upper eight bits of their bucket (8-byte records:
+// A one-level scatter (every workgroup writes each entry straight to its bucket's slot, cursors per workgroup and bucket) hands
+// every (chunk, bucket) pair its own few slots, so each 4-byte store lands in a line that no other store of the same workgroup
+// completes soon: the line leaves the L2 with four valid bytes and memory sees one partial write per entry (measured: 7.5 times the
+// entry bytes written, 2.35 ms per proof of 2^20 gates lost by the accumulation kernels beside it).  Here the entries first go to SORT_PARTS = 256 partitions by the upper eight bits of their bucket (8-byte records:
 // entry word + lower seven bits), each workgroup appending to its own reserved piece of a partition, so the 256 lines it has open
 // fill within an iteration or two; then one workgroup per partition spreads its records over the partition's 128 buckets, all
 // inside a region of about 256 KB that stays in the L2 until its lines are full.  Three launches; 1 KB of LDS per workgroup.
 constexpr int SORT_PARTS = 256, SORT_PART_BUCKETS = MSM_BUCKETS / SORT_PARTS;   // 128 buckets per partition
+constexpr int SORT_MAX_BLOCKS = 512;                                            // workgroups of the first two kernels (rows of the count matrix)
 static_assert(SORT_PART_BUCKETS == 128, "records keep seven bucket bits");
-// digits of every scalar (codes as in k_msm_digits) + this workgroup's histogram of partitions -> part_counts[workgroup][SORT_PARTS]
+// digits of every scalar (sixteen two-byte codes, 32 bytes per scalar) + this workgroup's histogram of partitions -> part_counts[workgroup][SORT_PARTS]
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ digits, uint32_t* __restrict__ part_counts) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t hist[SORT_PARTS];
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, segs.total);
+    uint32_t sw_next[8], ti;
+    if (lo + threadIdx.x < hi) load8(seg_scalar(segs, lo + threadIdx.x, &ti), sw_next);
     for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
-        uint32_t ti;
-        const uint32_t* sp = seg_scalar(segs, idx, &ti);
+        uint32_t sw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sw[i] = sw_next[i];
+        if (idx + SORT_THREADS < hi) load8(seg_scalar(segs, idx + SORT_THREADS, &ti), sw_next);   // in flight while this scalar is converted
         int32_t d[MSM_WINDOWS];
-        scalar_digits(sp, d);
+        scalar_digits(sw, d);
         uint32_t w[MSM_WINDOWS / 2];
 #pragma unroll
         for (int j = 0; j < MSM_WINDOWS; j += 2) {
-            const uint32_t c0 = d[j] == 0 ? DIGIT_NONE : ((d[j] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1));
-            const uint32_t c1 = d[j + 1] == 0 ? DIGIT_NONE : ((d[j + 1] < 0 ? 0x8000u : 0u) | (uint32_t)((d[j + 1] < 0 ? -d[j + 1] : d[j + 1]) - 1));
+            const uint32_t c0 = digit_code(d[j]), c1 = digit_code(d[j + 1]);
             w[j / 2] = c0 | (c1 << 16);
             if (c0 != DIGIT_NONE) atomicAdd(&hist[(c0 & 0x7fffu) >> 7], 1u);
             if (c1 != DIGIT_NONE) atomicAdd(&hist[(c1 & 0x7fffu) >> 7], 1u);
@@ -248,11 +142,15 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(MsmSegs segs, u
     }
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, segs.total);
+    uint32_t w_next[8];
+    if (lo + threadIdx.x < hi) load8(digits + 8ull * (lo + threadIdx.x), w_next);
     for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
         uint32_t ti;
         (void)seg_scalar(segs, idx, &ti);
         uint32_t w[8];
-        load8(digits + 8ull * idx, w);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = w_next[i];
+        if (idx + SORT_THREADS < hi) load8(digits + 8ull * (idx + SORT_THREADS), w_next);   // in flight while these codes are placed
 #pragma unroll
         for (int j = 0; j < MSM_WINDOWS; ++j) {
             const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
@@ -581,12 +479,10 @@ __global__ void __launch_bounds__(256) k_srs_generate(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------ host side
 static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     if (s.ready) return PLK_OK;
-    PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_count), hipFuncAttributeMaxDynamicSharedMemorySize, MSM_BUCKETS * 4));
-    PLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, MSM_BUCKETS * 4));
     PLK_HIP(hipEventCreateWithFlags(&s.sorted, hipEventDisableTiming));
     PLK_HIP(hipEventCreateWithFlags(&s.accumulated, hipEventDisableTiming));
     PLK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    PLK_HIP(hipMalloc(&s.counts, (size_t)MSM_MAX_BLOCKS * MSM_BUCKETS * 4));
+    PLK_HIP(hipMalloc(&s.counts, (size_t)SORT_MAX_BLOCKS * SORT_PARTS * 4));
     PLK_HIP(hipMalloc(&s.totals, (size_t)MSM_BUCKETS * 4));
     PLK_HIP(hipMalloc(&s.bucket_start, (size_t)(MSM_BUCKETS + 1) * 4));
     PLK_HIP(hipMalloc(&s.bucket_sums, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
@@ -716,25 +612,12 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         s.entries_cap = cap;
     }
     PLK_TRY(tails_reserve(ctx, s, acc_lanes(max_entries, acc_run(max_entries))));
-    // 8192 scalars per workgroup for long MSMs (fewer, longer runs per bucket and chunk: measured best at 2^20 scalars); shorter ones
-    // (the per-rank share of a sharded proof) are cut finer, down to 1024, so that they still occupy a good part of the chip
-    // two bucket ranges per chunk of scalars: measured best at 2^20 scalars (one range: pieces of 16 bytes per bucket and workgroup, most
-    // of them written to memory as separate 32-byte sectors; four ranges: the workgroups read every digit code four times over)
-    constexpr uint32_t log_split = 1;
-    const uint32_t split = 1u << log_split;
-    uint32_t per_block = 8192 * split;
-    while (per_block > 1024 && (uint64_t)((segs.total + per_block - 1) / per_block) * split < 128) per_block >>= 1;
-    uint32_t nblocks = (segs.total + per_block - 1) / per_block;
-    if (nblocks < 1) nblocks = 1;
-    if (nblocks > (uint32_t)MSM_MAX_BLOCKS) nblocks = MSM_MAX_BLOCKS;
-    const uint32_t chunk = (segs.total + nblocks - 1) / nblocks;
     hipStream_t st = lane ? lane : ctx->st_sort;
     bool idle = ctx->reduce_pending.empty();   // nothing of this context is running or queued on the device
     for (const auto& other : ctx->slot) idle = idle && (!other.busy || &other == &s);
     prof_begin(ctx, st, "msm_sort");
     uint32_t* digits = s.entries + s.entries_cap;      // 16 two-byte codes per scalar, at most entries_cap of them
-    static const bool one_level = getenv("PLK_SORT_ONE_LEVEL") != nullptr;   // the earlier sort, kept for comparison
-    if (!one_level) {
+    {
         uint64_t* records = reinterpret_cast<uint64_t*>(s.entries + s.entries_cap + s.entries_cap / 2);
         // Raised issue priority for every sort: given to the first four sorts of a round only, the later ones take twice as long, the
         // accumulation kernels 3 % less, and the proof the same or 0.1 ms more; to the first two only, 1.7 ms more.
@@ -749,21 +632,13 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         while (per > 1024 && (segs.total + per - 1) / per < 128) per >>= 1;
         uint32_t nb = (segs.total + per - 1) / per;
         if (nb < 1) nb = 1;
-        if (nb > 512) nb = 512;
+        if (nb > (uint32_t)SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
         const uint32_t ch = (segs.total + nb - 1) / nb;
         uint32_t* part_start = s.totals;               // SORT_PARTS + 1 words (the buffer holds MSM_BUCKETS)
         hipLaunchKernelGGL(k_sort_digits_count, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts);
         hipLaunchKernelGGL(k_sort_partition, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts, nb, part_start, (uint32_t)ctx->table_stride, records);
         if (fast) hipLaunchKernelGGL(k_sort_buckets<1024>, dim3(SORT_PARTS), dim3(1024), 0, st, records, part_start, s.bucket_start, s.entries);
         else hipLaunchKernelGGL(k_sort_buckets<SORT_THREADS>, dim3(SORT_PARTS), dim3(SORT_THREADS), 0, st, records, part_start, s.bucket_start, s.entries);
-    } else {
-    if (segs.total) hipLaunchKernelGGL(k_msm_digits, dim3((segs.total + 255) / 256), dim3(256), 0, st, segs, digits);
-    hipLaunchKernelGGL(k_msm_count, dim3(nblocks, split), dim3(SORT_THREADS), (MSM_BUCKETS >> log_split) * 4, st, digits, segs.total, chunk, s.counts, log_split);
-    hipLaunchKernelGGL(k_msm_totals, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.totals);
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(256), 0, st, s.totals, s.bucket_start);
-    hipLaunchKernelGGL(k_msm_offsets, dim3(MSM_BUCKETS / 256), dim3(256), 0, st, s.counts, nblocks, s.bucket_start);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks, split), dim3(SORT_THREADS), (MSM_BUCKETS >> log_split) * 4, st, segs, digits, chunk, s.counts, (uint32_t)ctx->table_stride, s.entries,
-                       log_split);
     }
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(s.sorted, st));
