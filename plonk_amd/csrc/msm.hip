@@ -585,13 +585,16 @@ static void clip_to_shard(const plk_ctx* ctx, const uint32_t* scalars, uint64_t 
     seg->table_off = (uint32_t)(lo - slo);
 }
 
-// Enqueues one MSM on the slot's stream: main segment (device scalars over powers_of_g) plus, when n_blind > 0 and this
-// shard holds the gamma powers, n_blind scalars (already in slot.blind_dev) over powers_of_gamma_g.
+// The stream for the front work (division, sort) of the next job: consecutive jobs alternate between the compute stream and the
+// reduction stream, so that the sort of one runs beside the division or sort of the next (0.2-0.3 ms per proof of 2^20 gates
+// against a single front stream).  Detached compute work and pending uploads own the reduction stream: then every job stays on the
+// compute stream.
 hipStream_t front_lane(plk_ctx* ctx) {
-    static const bool single = getenv("PLK_ONE_LANE") != nullptr;
-    if (single || ctx->detached || ctx->uploads_pending) return ctx->st_sort;
+    if (ctx->detached || ctx->uploads_pending) return ctx->st_sort;
     return (ctx->lane_turn++ & 1) ? ctx->st_red : ctx->st_sort;
 }
+// Enqueues one MSM: main segment (device scalars over powers_of_g) plus, when n_blind > 0 and this shard holds the gamma powers,
+// n_blind scalars (already in slot.blind_dev) over powers_of_gamma_g.  The sort goes to `lane` (st_sort when null).
 int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind, hipStream_t lane) {
     if (!ctx->tables) { ctx->err = "no SRS loaded"; return PLK_ERR_INVALID_ARG; }
     if (base_offset + k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
