@@ -78,24 +78,22 @@ PLK_HD void pack(const fe& a, uint32_t* w) {
     }
 }
 
-// acc + a * b as one v_mad_u64_u32.  Written as inline assembly on the device so that every column of a product stays ONE chain of
-// multiply-adds that starts from the carry of the column before: left to itself the compiler starts each column from zero (to have
-// independent chains) and then pays a 64-bit addition per column to bring the carry in.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PLK_ASM_MAD)
+// acc + a * b, one v_mad_u64_u32.  On the device every partial sum carries an assumption (true: the operand requirements of the
+// routines below keep a column below 2^64 - 2^56).  It generates no code, but gives the partial sum a second use, and the compiler's
+// reassociation pass only reorders sums whose intermediate values have a single use: without it the pass moves the carry that
+// starts a column to the end of the column's sum (it is the operand that becomes available last), and every column then costs a
+// 64-bit addition on top of its multiply-adds (17 per product).  Inline assembly per multiply-add has the same effect on the sum but
+// makes the compiler put a wait state after every statement, which costs more than the additions.
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint64_t mad_vv(uint32_t a, uint32_t b, uint64_t c) {
-    uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) {   // b: a constant (modulus limb), kept in a scalar register
-    uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
-    return d;
+    c += (uint64_t)a * b;
+    __builtin_assume((uint32_t)(c >> 32) != 0xffffffffu);
+    return c;
 }
 #else
 PLK_HD uint64_t mad_vv(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
-PLK_HD uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
 #endif
+PLK_HD uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) { return mad_vv(a, b, c); }   // b: a limb of the modulus
 
 // a * b * 2^-261 mod p (see the header comment for operand requirements); result normalized, bound 2
 template <class F>
