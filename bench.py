@@ -219,13 +219,28 @@ def main():
         if args.dist_backend == "nccl":
             # the exchange inside the library: rank 0's RCCL id travels through torch.distributed (which stays for the rendezvous, the
             # barriers and the timing reduction), the partial sums then go through ncclAllGather without passing through Python
+            ok, why = 1, ""
+            ids = [None]
             try:
-                ids = [pk.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
+                if rank == 0:
+                    ids[0] = pk.comm_unique_id()
+            except Exception as e:
+                why = str(e)
+            dist.broadcast_object_list(ids, src=0)            # every rank takes part, whether or not rank 0 obtained an id
+            try:
+                if ids[0] is None:
+                    raise RuntimeError(why or "rank 0 has no RCCL id")
                 pk.comm_init(ids[0], rank, world)
+            except Exception as e:
+                ok, why = 0, str(e)
+            # the ranks must agree: one rank on the library's exchange and another on the fallback would wait for each other for ever
+            agreed = torch.tensor([ok], dtype=torch.int32, device=gather_device)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 1:
                 collective = "ncclAllGather inside libplonk_hip (RCCL over xGMI)"
-            except Exception as e:       # fall back to the gather above, still RCCL
-                sys.stderr.write("library communicator unavailable (%s): partial sums go through torch.distributed\n" % e)
+            else:                        # fall back to the gather above, still RCCL
+                if why:
+                    sys.stderr.write("library communicator unavailable on rank %d (%s): partial sums go through torch.distributed\n" % (rank, why))
                 pk.set_sharding(rank, world, gather)
         else:
             pk.set_sharding(rank, world, gather)
