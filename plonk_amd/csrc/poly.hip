@@ -40,7 +40,11 @@ __global__ void __launch_bounds__(256) k_field_op(int op, const uint32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------ suffix Horner scan
-constexpr int DIV_L = 32;   // elements per thread
+#ifndef PLK_DIV_LOG_L
+#define PLK_DIV_LOG_L 5
+#endif
+constexpr int DIV_LOG_L = PLK_DIV_LOG_L;
+constexpr int DIV_L = 1 << DIV_LOG_L;   // elements per thread
 
 // Loads DIV_L/4 groups of four consecutive elements (one 128-byte line each) per lane, so that the per-lane walk over
 // consecutive coefficients still moves whole lines.
@@ -120,7 +124,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_sums(const uint32_t* __rest
     const fe z = to_rp(fe_of(zeta));
     fe s = div_local_sum(c, (uint64_t)blockIdx.x * DIV_BLOCK + (uint64_t)threadIdx.x * DIV_L, len, z);
     norm(s);
-    const fe tot = div_block_suffix_scan(s, div_pow2(z, 5), lds);   // thread 0 ends up with the whole block
+    const fe tot = div_block_suffix_scan(s, div_pow2(z, DIV_LOG_L), lds);   // thread 0 ends up with the whole block
     if (threadIdx.x == 0) st_lazy(A + 8ull * blockIdx.x, tot);
 }
 // carry[b] = h at the first coefficient of block b + 1 (zero for the last block); h0 = h_0, canonical.  One workgroup.
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __r
     __shared__ uint32_t tops[DIV_THREADS * 9];
     const uint32_t t = threadIdx.x;
     const uint32_t m = (nb + DIV_THREADS - 1) / DIV_THREADS;            // blocks per thread
-    const fe ze = div_pow2(to_rp(fe_of(zeta)), 13);                     // z^8192
+    const fe ze = div_pow2(to_rp(fe_of(zeta)), 8 + DIV_LOG_L);          // z^DIV_BLOCK
     // weight between the chunks of neighbouring threads: ze^m
     fe wm = fe_const(FrP::ONE);
     for (uint32_t k = 0; k < m; ++k) wm = mul<FrP>(wm, ze);
@@ -178,7 +182,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __res
         if (!need) return;
     }
     const fe z = to_rp(fe_of(zeta));
-    const fe zl = div_pow2(z, 5);
+    const fe zl = div_pow2(z, DIV_LOG_L);
     const uint64_t lo = (uint64_t)blk * DIV_BLOCK + (uint64_t)t * DIV_L;
     const fe cin = ld_fe(carry + 8ull * blk);
     fe s = div_local_sum(c, lo, len, z);
