@@ -397,13 +397,14 @@ from plonk_amd import synth
 from plonk_amd.prover import ProverKey
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-tables = synth.circuit_tables(*synth.synthetic_circuit(8, seed=4))
+log_gates, log_block = int(sys.argv[4]), int(sys.argv[5])
+tables = synth.circuit_tables(*synth.synthetic_circuit(log_gates, seed=4))
 total = 4 * tables["n"] + 1
 per = (total + world - 1) // world
 pk = ProverKey(0)
 tau, gs = synth.seeded_scalars(2, 7)
 if sys.argv[3] == "cyclic":
-    pk.generate_srs_cyclic(tau, gs, total, rank, world, log_block=5)
+    pk.generate_srs_cyclic(tau, gs, total, rank, world, log_block=log_block)
 else:
     pk.generate_srs(tau, gs, total, shard_first=rank * per, shard_len=min(per, total - rank * per))
 def gather(mine):
@@ -420,22 +421,23 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("layout", ["contiguous", "cyclic"])
-def test_sharded_proof_two_processes(orc, tmp_path, layout):
-    """Two ranks (gloo, both on this box's one GPU): each holds half of the SRS (one contiguous range, or every second block),
-    partial sums are all-gathered, and both ranks finish with the proof the unsharded prover and the CPU oracle produce."""
+@pytest.mark.parametrize("layout,world,log_gates,log_block", [("contiguous", 2, 8, 5), ("cyclic", 2, 8, 5), ("cyclic", 4, 14, 12)])
+def test_sharded_proof_several_processes(orc, tmp_path, layout, world, log_gates, log_block):
+    """Several ranks (gloo, all on this box's one GPU): each holds its share of the SRS (one contiguous range, or every world-th
+    block; the last case uses the block size and rank count of a real 4-GPU run on a 2^14-gate circuit), partial sums are
+    all-gathered, and every rank finishes with the proof the unsharded prover and the CPU oracle produce."""
     from plonk_amd.prover import ProverKey
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path), layout], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path), layout, str(log_gates), str(log_block)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=280)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
-    proofs = [open(tmp_path / ("proof%d.bin" % r), "rb").read() for r in range(2)]
-    assert proofs[0] == proofs[1]
-    tables = synth.circuit_tables(*synth.synthetic_circuit(8, seed=4))
+    proofs = [open(tmp_path / ("proof%d.bin" % r), "rb").read() for r in range(world)]
+    assert all(p == proofs[0] for p in proofs)
+    tables = synth.circuit_tables(*synth.synthetic_circuit(log_gates, seed=4))
     pk = ProverKey(0)
     tau, gs = synth.seeded_scalars(2, 7)
     pk.generate_srs(tau, gs, 4 * tables["n"] + 1)
@@ -444,7 +446,7 @@ def test_sharded_proof_two_processes(orc, tmp_path, layout):
     inputs = pk.prepare(tables)
     single = pk.prove(inputs, synth.seeded_scalars(27, 8)).proof_bytes
     g = pk.ctx.srs_read(0, 0, 4 * tables["n"] + 1); gg = pk.ctx.srs_read(1, 0, 3)
-    rc, want, _, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], 8, synth.seeded_scalars(27, 8), chal)
+    rc, want, _, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], log_gates, synth.seeded_scalars(27, 8), chal)
     assert rc == 0 and single == want == proofs[0]
     inputs.close(); pk.close()
 
