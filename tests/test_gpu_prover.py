@@ -300,3 +300,42 @@ def test_proof_from_host_arrays_equals_the_resident_one(pk, orc, log_n):
     for h in pinned:
         pk.ctx.host_free(h)
     inputs.close()
+
+
+def test_two_keys_driven_by_two_threads(orc):
+    """Two prover keys on one GPU, each driven by its own host thread (the keys share the device's streams, everything else is per
+    key): every proof of either thread has the bytes the oracle produces."""
+    import threading
+    from plonk_amd.prover import ProverKey
+    log_n = 12
+    tables = synth.circuit_tables(*synth.synthetic_circuit(log_n, seed=9))
+    n4 = 4 * tables["n"]
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    blinds = synth.seeded_scalars(27, 21)
+    chal = synth.to_mont([0x5EED5EED5EED5EED1234])[0]
+    keys = []
+    for _ in range(2):
+        k = ProverKey(0)
+        k.generate_srs(tau, gs, n4 + 1)
+        k.set_opening_challenge(chal)
+        keys.append((k, k.prepare(tables)))
+    polys = independent_polys(orc, tables)
+    one = orc.fr_from_ints([1])[0]
+    g = orc.srs_powers(tau, one, 0, n4 + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+    rc, want, _, _ = orc.prove(g, gg, polys, tables["witness_flat"], tables["sigma"], log_n, blinds, chal)
+    assert rc == 0
+    results = [[], []]
+
+    def run(i):
+        k, inputs = keys[i]
+        for _ in range(12):
+            results[i].append(k.prove(inputs, blinds).proof_bytes)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=100)
+    assert not any(t.is_alive() for t in threads), "a prover thread did not finish"
+    for i in range(2):
+        assert len(results[i]) == 12 and all(p == want for p in results[i])
+    for k, inputs in keys:
+        inputs.close(); k.close()
