@@ -628,10 +628,11 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         // (every workgroup of the partitioning kernel reads the whole count matrix).  Measured inside a proof of 2^20 gates: 4096 scalars
         // per workgroup the same, 16384 0.6 ms slower; four workgroups per partition in the second level (1024 workgroups, two launches)
         // halve the isolated sort and make the proof 0.7 ms slower; without the raised issue priority 0.9 ms slower.
-        // The first sort of a round finds the chip idle and the round waiting for it: twice as many workgroups in the first level,
+        // The first sort of a round finds the chip idle and the round waiting for it: four times as many workgroups in the first level
+        // (two per CU at 2^20 scalars; 0.1 ms per proof better than twice as many, workgroups of 512 or 1024 threads instead: no better),
         // sixteen waves per partition in the second (0.2 ms per proof).
         const bool fast = idle;
-        uint32_t per = fast ? 4096 : 8192;
+        uint32_t per = fast ? 2048 : 8192;
         while (per > 1024 && (segs.total + per - 1) / per < 128) per >>= 1;
         uint32_t nb = (segs.total + per - 1) / per;
         if (nb < 1) nb = 1;
