@@ -25,7 +25,7 @@ WINDOWS = 16                # 16-bit signed windows over 254-bit scalars
 MODMUL_PER_MADD = 10        # XYZZ mixed addition: 8 M + 2 S
 MADS_PER_MODMUL = 136       # 8x8 + 8x8 + 8 multiply-adds of an 8x32-bit-limb Montgomery product (the algorithmic count)
 # HBM-side bytes of k_msm_accumulate per (point, window) entry, from rocprofv3 PMC passes over this same command
-# (FETCH_SIZE 1.419 GB + WRITE_SIZE 0.044 GB per launch of 18.64 M entries on average; profiles/r02c_bench20_pmc_*.txt;
+# (FETCH_SIZE 1.419 GB + WRITE_SIZE 0.044 GB per launch of 18.64 M entries on average; profiles/r02d_bench20_pmc_*.txt;
 # the r02b pass measured 1.359 GB: the share of the gathers served by the last-level cache varies from run to run).
 # The algorithmic figure is 64 B table point + 4 B sorted entry = 68 B.
 ACC_TRAFFIC_BYTES_PER_ENTRY = 78.5
@@ -343,7 +343,7 @@ def main():
     roofline = {
         "kernel": "k_msm_accumulate", "bound": "valu_int", "achieved": round(achieved / 1e12, 3), "peak": MAD_PEAK / 1e12,
         "unit": "T mad/s (algorithmic 32-bit multiply-adds: pairs x 16 windows x 10 modmul x 136)", "frac": round(achieved / MAD_PEAK, 4),
-        "traffic": round(traffic_per_launch), "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r02c_bench20_pmc_*.txt)",
+        "traffic": round(traffic_per_launch), "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r02d_bench20_pmc_*.txt)",
         "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_proof": int(launches_per_proof),
         "pairs_per_launch_avg": int(pairs_per_launch),
         "overlap": {"note": "launches alternate between two streams and overlap; busy = time with at least one launch running",
