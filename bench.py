@@ -370,7 +370,7 @@ def main():
     if incl:
         out["value_incl_h2d_ms"] = incl["pinned_ms"]
         out["incl_h2d"] = dict(incl, note="host arrays in, proof out (the call shape of src/prover.rs:119-133): the inputs cross PCIe while the first commitments "
-                                          "run; pinned = page-locked host arrays (plk_host_malloc), pageable = ordinary numpy arrays staged by the runtime")
+                                          "run; pinned = page-locked host arrays (plk_host_malloc), pageable = ordinary numpy arrays, which the library copies through its ring of page-locked buffers with helper threads")
     if args.ntt_log_n:
         try:
             import torch as _torch

@@ -48,7 +48,8 @@ int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_src, uint64_t
  * transfer is enqueued on a stream of its own and every LATER call on this context that reads dev_dst is ordered after it, so the
  * commitment of the first polynomial runs while the others are still crossing PCIe.  host_src must stay valid until a call that
  * returns results of work reading dev_dst has returned (or plk_sync).  From pinned memory (plk_host_malloc) the call returns at
- * once and the transfer runs at link speed; from ordinary memory it is correct but the runtime stages it and the call blocks. */
+ * once and the transfer runs at link speed; ordinary memory (a Rust Vec, a std::vector) goes through a ring of page-locked buffers
+ * filled by helper threads of the library, at link speed as well, and the call returns when the array has been copied out. */
 int32_t plk_upload_enqueue(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
 /* page-locked host memory for plk_upload_enqueue */
 int32_t plk_host_malloc(plk_ctx* ctx, uint64_t bytes, void** host);

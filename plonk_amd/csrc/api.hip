@@ -1,6 +1,9 @@
 // Context lifecycle, device memory helpers, measurement hooks and the KZG commit / open entry points.
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include "common.cuh"
 #include "host_math.hpp"
 #include "kernels.h"
@@ -161,6 +164,99 @@ void streams_release(plk_ctx* ctx) {
 }
 }  // namespace
 
+// ---- ordinary (pageable) host arrays -----------------------------------------------------------
+// hipMemcpyAsync from pageable memory is staged by the runtime on the calling thread: 26 GB/s on the MI355X host against 52 GB/s from
+// page-locked memory, and the call blocks meanwhile.  A caller that hands over ordinary vectors (the reference's &DensePolynomial /
+// &[Fr]) gets the same link rate here: the array goes through a ring of page-locked buffers, copied into them by a few helper
+// threads and the calling thread together (one thread moves 24-27 GB/s, four 75 GB/s), each buffer's transfer enqueued as soon
+// as it is full.  hipHostRegister, which would avoid the copy, is refused on this system (invalid argument).
+namespace {
+struct StagePool {
+    static constexpr int SLOTS = 4, HELPERS = 3;
+    static constexpr size_t CHUNK = 16u << 20;
+    char* buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t copied[SLOTS] = {nullptr, nullptr, nullptr, nullptr};   // the transfer out of the buffer has finished
+    bool used[SLOTS] = {false, false, false, false};
+    unsigned next = 0;
+    struct Task { char* dst; const char* src; size_t n; };
+    std::vector<std::thread> helpers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Task> queue;
+    int pending = 0;
+    bool stop = false;
+
+    void helper() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv_work.wait(lock, [&] { return stop || !queue.empty(); });
+                if (queue.empty()) return;   // stop
+                t = queue.front();
+                queue.pop_front();
+            }
+            memcpy(t.dst, t.src, t.n);
+            {
+                std::lock_guard<std::mutex> lock(m);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    // dst[0, n) = src[0, n), the helpers and the caller each taking a share; returns when all of it is in place
+    void copy(char* dst, const char* src, size_t n) {
+        const size_t parts = HELPERS + 1;
+        const size_t per = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        size_t own_off = 0, own_n = std::min(per, n);
+        {
+            std::lock_guard<std::mutex> lock(m);
+            for (size_t off = per; off < n; off += per) {
+                queue.push_back({dst + off, src + off, std::min(per, n - off)});
+                ++pending;
+            }
+        }
+        cv_work.notify_all();
+        memcpy(dst + own_off, src + own_off, own_n);
+        std::unique_lock<std::mutex> lock(m);
+        cv_done.wait(lock, [&] { return pending == 0; });
+    }
+    bool init() {
+        for (int i = 0; i < SLOTS; ++i) {
+            if (hipHostMalloc((void**)&buf[i], CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+        for (int i = 0; i < HELPERS; ++i) helpers.emplace_back([this] { helper(); });
+        return true;
+    }
+    ~StagePool() {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto& t : helpers) t.join();
+        for (int i = 0; i < SLOTS; ++i) {
+            if (copied[i]) (void)hipEventDestroy(copied[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+        }
+    }
+};
+StagePool* stage_pool(plk_ctx* ctx) {
+    if (!ctx->stage) {
+        StagePool* sp = new StagePool();
+        if (!sp->init()) { delete sp; return nullptr; }
+        ctx->stage = sp;
+    }
+    return static_cast<StagePool*>(ctx->stage);
+}
+// page-locked (hipHostMalloc / registered) host memory: the runtime transfers from it directly
+bool host_memory_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
 extern "C" int32_t plk_create(int32_t device, plk_ctx** out) {
     if (!out) return PLK_ERR_INVALID_ARG;
     int count = 0;
@@ -196,6 +292,8 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
     if (ctx->comm) plk_comm_destroy(ctx);
     for (auto& s : ctx->slot) slot_destroy(s);
+    delete static_cast<StagePool*>(ctx->stage);
+    ctx->stage = nullptr;
     ntt_release(ctx);
     hipFree(ctx->tables); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
     streams_release(ctx);
@@ -223,15 +321,34 @@ extern "C" int32_t plk_upload(plk_ctx* ctx, void* dev_dst, const void* host_src,
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     return PLK_OK;
 }
-// Upload that does not wait: the copy runs on the detached stream (st_red, idle at the start of a round), and the stream that carries
-// the compute work and the MSM sorts is ordered after it from this call on.  Later calls that read dev_dst therefore see the data,
-// earlier ones are not held up, and the transfers of several such calls follow each other without gaps.
+// Upload that does not wait for the transfer: the copy runs on the detached stream (st_red, idle at the start of a round), and the stream
+// that carries the compute work and the MSM sorts is ordered after it from this call on.  Later calls that read dev_dst therefore see the
+// data, earlier ones are not held up, and the transfers of several such calls follow each other without gaps.  host_src may be reused
+// when the call returns if it is ordinary memory (it has been copied out), page-locked memory must stay untouched until the transfer
+// has run (plk_sync or any later result that depends on it).
 extern "C" int32_t plk_upload_enqueue(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes) {
     if (!ctx || (bytes && (!dev_dst || !host_src))) return PLK_ERR_INVALID_ARG;
     if (!bytes) return PLK_OK;
     PLK_HIP(hipSetDevice(ctx->device));
     ctx->uploads_pending = true;
-    PLK_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->st_red));
+    StagePool* sp = bytes >= (1u << 20) && !host_memory_is_pinned(host_src) ? stage_pool(ctx) : nullptr;
+    if (sp) {
+        // ordinary memory: through the page-locked ring, one buffer's worth at a time; the call returns when the last piece has been
+        // copied into the ring and its transfer enqueued (the transfers themselves are not waited for)
+        const char* src = static_cast<const char*>(host_src);
+        char* dst = static_cast<char*>(dev_dst);
+        for (uint64_t off = 0; off < bytes; off += StagePool::CHUNK) {
+            const size_t n = (size_t)std::min<uint64_t>(StagePool::CHUNK, bytes - off);
+            const int slot = (int)(sp->next++ % StagePool::SLOTS);
+            if (sp->used[slot]) PLK_HIP(hipEventSynchronize(sp->copied[slot]));   // the buffer's previous transfer
+            sp->copy(sp->buf[slot], src + off, n);
+            PLK_HIP(hipMemcpyAsync(dst + off, sp->buf[slot], n, hipMemcpyHostToDevice, ctx->st_red));
+            PLK_HIP(hipEventRecord(sp->copied[slot], ctx->st_red));
+            sp->used[slot] = true;
+        }
+    } else {
+        PLK_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->st_red));
+    }
     hipEvent_t ev;
     PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     PLK_HIP(hipEventRecord(ev, ctx->st_red));

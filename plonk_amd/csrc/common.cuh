@@ -112,6 +112,7 @@ struct plk_ctx {
     hipStream_t quotient_stream = nullptr;   // stream of a quotient enqueued with plk_quotient_dev_enqueue and not yet finished
     uint32_t* flag_dev = nullptr;
     uint32_t* flag_host = nullptr;
+    void* stage = nullptr;             // staging of ordinary (pageable) host arrays for plk_upload_enqueue: page-locked ring + copy threads, made on first use
     // RCCL communicator of the ranks that share one proof (plk_comm_init), with its staging buffers
     void* comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;

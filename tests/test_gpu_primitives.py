@@ -439,3 +439,29 @@ def test_many_coset_generators(ctx, orc):
         ctx.ntt_dev(d, log_n, inverse=True, coset=g)
     assert np.array_equal(ctx.download(d, (1 << log_n, 4)), a)
     ctx.free(d)
+
+
+def test_upload_enqueue_from_ordinary_and_page_locked_memory(ctx):
+    """plk_upload_enqueue: ordinary arrays travel through the library's staging ring (helper threads, 16 MB buffers, four of them),
+    page-locked ones directly; sizes below, at and across the buffer size, several uploads in a row, odd byte counts."""
+    rng = np.random.default_rng(77)
+    sizes = [5, 1 << 20, (1 << 20) + 3, (16 << 20) - 1, 16 << 20, (16 << 20) + 4097, (80 << 20) + 11]
+    dev = [ctx.malloc(n) for n in sizes]
+    host = [rng.integers(0, 256, size=n, dtype=np.uint8) for n in sizes]
+    for d, h in zip(dev, host):
+        ctx.upload_enqueue(d, h)
+    ctx.sync()
+    for d, h in zip(dev, host):
+        assert np.array_equal(ctx.download(d, h.shape, np.uint8), h)
+    # the same buffers again from page-locked memory, with other contents
+    pinned = []
+    for d, h in zip(dev, host):
+        p = ctx.host_empty(h.shape, np.uint8); p[...] = h[::-1]; pinned.append(p)
+        ctx.upload_enqueue(d, p)
+    ctx.sync()
+    for d, p in zip(dev, pinned):
+        assert np.array_equal(ctx.download(d, p.shape, np.uint8), p)
+    for p in pinned:
+        ctx.host_free(p)
+    for d in dev:
+        ctx.free(d)

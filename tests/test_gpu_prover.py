@@ -272,11 +272,12 @@ def test_cxx_replay_of_the_reference_driver(pk, orc):
     assert lines[0] == "proof " + want.hex()
 
 
-@pytest.mark.parametrize("log_n", [3, 10, 14])
+@pytest.mark.parametrize("log_n", [3, 10, 14, 19])
 def test_proof_from_host_arrays_equals_the_resident_one(pk, orc, log_n):
     """create_plonk_proof_with_transcript on borrowed host arrays (src/prover.rs:119-133): the polynomials are uploaded by the prover
     itself while its first commitments run.  Same bytes as the proof of inputs that were resident beforehand, from ordinary and from
-    page-locked arrays, and again after a proof of another size has used the same device buffers."""
+    page-locked arrays, and again after a proof of another size has used the same device buffers.  At 2^19 gates the ordinary arrays
+    go several times round the library's ring of staging buffers (64 MB of s_sigma, 48 MB of witness values)."""
     variables, gates = synth.synthetic_circuit(log_n, seed=40 + log_n)
     tables = synth.circuit_tables(variables, gates)
     tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
