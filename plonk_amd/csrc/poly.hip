@@ -40,13 +40,7 @@ __global__ void __launch_bounds__(256) k_field_op(int op, const uint32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------ suffix Horner scan
-#ifndef PLK_DIV_LOG_L
-#define PLK_DIV_LOG_L 5
-#endif
-constexpr int DIV_LOG_L = PLK_DIV_LOG_L;
-constexpr int DIV_L = 1 << DIV_LOG_L;   // elements per thread
-
-// Loads DIV_L/4 groups of four consecutive elements (one 128-byte line each) per lane, so that the per-lane walk over
+// Loads groups of four consecutive elements (one 128-byte line each) per lane, so that the per-lane walk over
 // consecutive coefficients still moves whole lines.
 __device__ __forceinline__ void load_quad(const uint32_t* __restrict__ c, uint64_t i0, uint64_t len, fe out[4]) {
     if (i0 + 4 <= len) {
@@ -65,22 +59,30 @@ __device__ __forceinline__ void load_quad(const uint32_t* __restrict__ c, uint64
     }
 }
 
-// Three kernels whatever the length.  A workgroup of 256 threads owns DIV_BLOCK = 8192 consecutive coefficients, a thread DIV_L = 32:
+// Three kernels whatever the length.  A workgroup of 256 threads owns E = 256 L consecutive coefficients, a thread L = 2^LOG_L:
 //   k_div_sums    A_b = sum_{i in block b} c_i z^(i - b E)                      (thread-local Horner, weighted tree over the block)
 //   k_div_carries C_b = A_b + z^E C_{b+1}: suffix scan over the blocks by one workgroup -> carry into every block, and h_0
 //   k_div_apply   thread-local Horner again, weighted suffix scan inside the block seeded with the block's carry, then the walk
-//                 down the thread's 32 coefficients that writes scale * h_i
+//                 down the thread's L coefficients that writes scale * h_i
 // (the coefficients are read three times, twice of them from L2; a scan with one kernel per level of a 32-ary tree took nine
 // launches at 2^20 coefficients, most of them a few microseconds of work behind 25 microseconds of launch latency).
+// L = 8 below 2^21 coefficients, 32 from there on.  A thread's Horner chain is L dependent products and a polynomial of n
+// coefficients gives n / (256 L) workgroups: with L = 32 a polynomial of 2^16 coefficients is eight workgroups on 256 CUs whose
+// every thread walks through 32 dependent products, and the division takes as long as at 2^20 coefficients (0.18 ms); measured
+// alone, 2^20 coefficients take 0.17 ms with L = 8 and 0.22 ms with L = 32, 2^22 coefficients 0.41 against 0.35 ms.
 constexpr int DIV_THREADS = 256;
-constexpr int DIV_BLOCK = DIV_THREADS * DIV_L;
+constexpr int DIV_LOG_L_SHORT = 3, DIV_LOG_L_LONG = 5;
+constexpr uint64_t DIV_LONG_FROM = 1ull << 21;
+static int div_log_l(uint64_t len) { return len < DIV_LONG_FROM ? DIV_LOG_L_SHORT : DIV_LOG_L_LONG; }
+static uint64_t div_block(uint64_t len) { return (uint64_t)DIV_THREADS << div_log_l(len); }
 
 // S = sum_{k < L} c_{lo + k} z^k; coefficients past len count as zero.  Result bound 3, limbs < 2^30.
+template <int LOG_L>
 __device__ __forceinline__ fe div_local_sum(const uint32_t* __restrict__ c, uint64_t lo, uint64_t len, const fe& z) {
     fe h = fe_zero();
     if (lo >= len) return h;
 #pragma unroll 1
-    for (int q = DIV_L / 4 - 1; q >= 0; --q) {
+    for (int q = (1 << LOG_L) / 4 - 1; q >= 0; --q) {
         fe v[4];
         load_quad(c, lo + 4 * q, len, v);
 #pragma unroll
@@ -118,23 +120,25 @@ __device__ __forceinline__ fe div_pow2(fe x, int squarings) {
     return x;
 }
 
+template <int LOG_L>
 __global__ void __launch_bounds__(DIV_THREADS) k_div_sums(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, uint32_t* __restrict__ A) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     const fe z = to_rp(fe_of(zeta));
-    fe s = div_local_sum(c, (uint64_t)blockIdx.x * DIV_BLOCK + (uint64_t)threadIdx.x * DIV_L, len, z);
+    fe s = div_local_sum<LOG_L>(c, ((uint64_t)blockIdx.x * DIV_THREADS + threadIdx.x) << LOG_L, len, z);
     norm(s);
-    const fe tot = div_block_suffix_scan(s, div_pow2(z, DIV_LOG_L), lds);   // thread 0 ends up with the whole block
+    const fe tot = div_block_suffix_scan(s, div_pow2(z, LOG_L), lds);   // thread 0 ends up with the whole block
     if (threadIdx.x == 0) st_lazy(A + 8ull * blockIdx.x, tot);
 }
 // carry[b] = h at the first coefficient of block b + 1 (zero for the last block); h0 = h_0, canonical.  One workgroup.
-__global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __restrict__ A, uint32_t nb, W8 zeta, uint32_t* __restrict__ carry, uint32_t* __restrict__ h0_out) {
+__global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __restrict__ A, uint32_t nb, W8 zeta, int log_block, uint32_t* __restrict__ carry,
+                                                             uint32_t* __restrict__ h0_out) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     __shared__ uint32_t tops[DIV_THREADS * 9];
     const uint32_t t = threadIdx.x;
     const uint32_t m = (nb + DIV_THREADS - 1) / DIV_THREADS;            // blocks per thread
-    const fe ze = div_pow2(to_rp(fe_of(zeta)), 8 + DIV_LOG_L);          // z^DIV_BLOCK
+    const fe ze = div_pow2(to_rp(fe_of(zeta)), log_block);              // z^E
     // weight between the chunks of neighbouring threads: ze^m
     fe wm = fe_const(FrP::ONE);
     for (uint32_t k = 0; k < m; ++k) wm = mul<FrP>(wm, ze);
@@ -165,27 +169,29 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __r
     if (t == 0 && h0_out) st_fe<FrP>(h0_out, mul<FrP>(h, fe_const(FrP::ONE)));
 }
 // q_out[i - 1] = scale * h_i for i >= 1
+template <int LOG_L>
 __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry,
                                                            uint32_t* __restrict__ q_out, W8 scale, uint32_t first_block, uint32_t cyc_world, uint32_t cyc_rank,
                                                            uint32_t cyc_log_block) {
     PLK_SIDE_PRIO();
+    constexpr uint64_t BLOCK = (uint64_t)DIV_THREADS << LOG_L;
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     __shared__ uint32_t heads[DIV_THREADS * 9];
     const uint32_t t = threadIdx.x, blk = first_block + blockIdx.x;
     if (cyc_world > 1) {
         // block-cyclic shard: q_out[k] is only used for the SRS points k this rank holds (block k >> log_block congruent to rank);
         // a workgroup whose coefficients (k = i - 1) touch none of them has nothing to write
-        const uint64_t k_lo = blk == 0 ? 0 : (uint64_t)blk * DIV_BLOCK - 1, k_hi = (uint64_t)blk * DIV_BLOCK + DIV_BLOCK - 2;
+        const uint64_t k_lo = blk == 0 ? 0 : (uint64_t)blk * BLOCK - 1, k_hi = (uint64_t)blk * BLOCK + BLOCK - 2;
         const uint64_t b_lo = k_lo >> cyc_log_block, b_hi = k_hi >> cyc_log_block;
         bool need = b_hi - b_lo + 1 >= cyc_world;
         for (uint64_t b = b_lo; !need && b <= b_hi; ++b) need = b % cyc_world == cyc_rank;
         if (!need) return;
     }
     const fe z = to_rp(fe_of(zeta));
-    const fe zl = div_pow2(z, DIV_LOG_L);
-    const uint64_t lo = (uint64_t)blk * DIV_BLOCK + (uint64_t)t * DIV_L;
+    const fe zl = div_pow2(z, LOG_L);
+    const uint64_t lo = (uint64_t)blk * BLOCK + ((uint64_t)t << LOG_L);
     const fe cin = ld_fe(carry + 8ull * blk);
-    fe s = div_local_sum(c, lo, len, z);
+    fe s = div_local_sum<LOG_L>(c, lo, len, z);
     if (t == DIV_THREADS - 1) s = add(s, mul<FrP>(cin, zl));            // h at this thread's first coefficient, given the block's carry
     norm(s);
     const fe head = div_block_suffix_scan(s, zl, lds);                  // h at every thread's first coefficient
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __res
     }
     const fe sc = to_rp(fe_of(scale));
 #pragma unroll 1
-    for (int q = DIV_L / 4 - 1; q >= 0; --q) {
+    for (int q = (1 << LOG_L) / 4 - 1; q >= 0; --q) {
         fe v[4];
         load_quad(c, lo + 4 * q, len, v);
 #pragma unroll
@@ -214,7 +220,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __res
 }
 
 uint64_t division_work_words(uint64_t len) {
-    const uint64_t nb = (len + DIV_BLOCK - 1) / DIV_BLOCK;
+    const uint64_t block = div_block(len), nb = (len + block - 1) / block;
     return 2 * (nb + 1) * 8 + 64;
 }
 int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
@@ -224,20 +230,24 @@ int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, u
         if (h0_out) PLK_HIP(hipMemsetAsync(h0_out, 0, 32, st));
         return PLK_OK;
     }
-    const uint32_t nb = (uint32_t)((len + DIV_BLOCK - 1) / DIV_BLOCK);
+    const bool is_short = div_log_l(len) == DIV_LOG_L_SHORT;
+    const uint64_t block = div_block(len);
+    const uint32_t nb = (uint32_t)((len + block - 1) / block);
     uint32_t* A = work;
     uint32_t* carry = work + (size_t)(nb + 1) * 8;
     const W8 z = w8_of(zeta);
     prof_begin(ctx, st, "division");
-    hipLaunchKernelGGL(k_div_sums, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, A);
-    hipLaunchKernelGGL(k_div_carries, dim3(1), dim3(DIV_THREADS), 0, st, A, nb, z, carry, h0_out);
+    if (is_short) hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_SHORT>, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, A);
+    else hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_LONG>, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, A);
+    hipLaunchKernelGGL(k_div_carries, dim3(1), dim3(DIV_THREADS), 0, st, A, nb, z, 8 + div_log_l(len), carry, h0_out);
     if (q_out && len > 1 && q_count > 0) {
         // q_out[k] comes from coefficient k + 1: only the blocks that hold coefficients q_first + 1 .. q_first + q_count are walked
         const uint64_t hi = std::min<uint64_t>(q_first + q_count, len - 1);
         if (q_first < hi) {
-            const uint32_t b0 = (uint32_t)((q_first + 1) / DIV_BLOCK), b1 = (uint32_t)(hi / DIV_BLOCK);
-            hipLaunchKernelGGL(k_div_apply, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, w8_of(scale ? scale : host::FR.one), b0,
-                               cw, cr, cl);
+            const uint32_t b0 = (uint32_t)((q_first + 1) / block), b1 = (uint32_t)(hi / block);
+            const W8 sc = w8_of(scale ? scale : host::FR.one);
+            if (is_short) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_SHORT>, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, sc, b0, cw, cr, cl);
+            else hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_LONG>, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, sc, b0, cw, cr, cl);
         }
     }
     prof_end(ctx, st);
@@ -581,7 +591,8 @@ extern "C" int32_t plk_poly_eval(plk_ctx* ctx, const uint64_t* coeffs_host, uint
 // k_div_carries reads them), so nothing has to be cleared between calls; two calls that overlap on one GPU would share the
 // array and race.
 constexpr uint64_t EVAL_STATIC_MAX_LEN = PLK_POLY_EVAL_STATIC_MAX_LEN;
-constexpr uint64_t EVAL_STATIC_WORDS = 2 * (EVAL_STATIC_MAX_LEN / plk::DIV_BLOCK + 1) * 8 + 64;   // = division_work_words(EVAL_STATIC_MAX_LEN): 524,608 bytes
+constexpr uint64_t EVAL_STATIC_WORDS = 2 * (EVAL_STATIC_MAX_LEN / ((uint64_t)plk::DIV_THREADS << plk::DIV_LOG_L_LONG) + 1) * 8 + 64;   // = division_work_words(EVAL_STATIC_MAX_LEN): 524,608 bytes
+static_assert(2 * (plk::DIV_LONG_FROM / ((uint64_t)plk::DIV_THREADS << plk::DIV_LOG_L_SHORT) + 1) * 8 + 64 <= EVAL_STATIC_WORDS, "the short form's block sums fit as well");
 static __device__ __align__(256) uint32_t scratch[EVAL_STATIC_WORDS];
 namespace {
 constexpr int STATIC_MAX_DEVICES = 64;

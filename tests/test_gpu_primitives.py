@@ -312,15 +312,15 @@ def test_kzg_commit_open(ctx, orc, srs, length):
 
 
 def test_kzg_open_lengths_around_the_division_blocks(orc):
-    """The division by (X - zeta) works in blocks of 8192 coefficients with a carry across blocks: lengths on both sides of one, two
-    and several block boundaries, against the oracle's long division and MSM."""
+    """The division by (X - zeta) works in blocks of 2048 coefficients (8192 from 2^21 coefficients on, see the scale tests) with a
+    carry across blocks: lengths on both sides of one, two and several block boundaries, against the oracle's long division and MSM."""
     from plonk_amd.hip import Context
     c = Context(0)
     n = 1 << 16
     tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
     c.srs_generate(tau, gs, n + 1)
     g = c.srs_read(0, 0, n + 1); gg = c.srs_read(1, 0, 3)
-    for length in (8191, 8192, 8193, 16384, 16385, 24577, 40000, 65536, 65537):
+    for length in (2047, 2048, 2049, 4096, 4097, 6145, 8191, 8192, 8193, 16384, 16385, 24577, 40000, 65536, 65537):
         coeffs = rand_fr(orc, length, 90 + length)
         blind = rand_fr(orc, 3, 91 + length)
         zeta, chal = rand_fr(orc, 2, 92 + length)

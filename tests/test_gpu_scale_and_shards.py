@@ -134,6 +134,41 @@ def _random_residues(count, seed):
     return raw
 
 
+@pytest.mark.parametrize("length", [(1 << 21) - 1, 1 << 21, (1 << 21) + 1, (1 << 21) + 8193, 3 * (1 << 20) + 5])
+def test_division_around_the_change_of_block_size(orc, length):
+    """Polynomials of 2^21 coefficients and more are divided in blocks of 8192 coefficients, shorter ones in blocks of 2048: the
+    evaluation (the division's remainder) against the oracle's Horner pass, and the quotient through its commitment and the SRS
+    trapdoor, (tau - zeta) W = c C - c v G - random_v gamma G, on both sides of the change."""
+    from plonk_amd.hip import Context
+    c = Context(0)
+    tau, gs = synth.seeded_scalars(2, 51)
+    c.srs_generate(tau, gs, length + 1)
+    coeffs = _random_residues(length, 52)
+    blind = synth.seeded_scalars(3, 53)
+    zeta = synth.seeded_scalars(1, 54)[0]
+    chal = synth.to_mont([0x1F2E3D4C5B6A79881122334455667788])[0]
+    ev = orc.poly_eval(coeffs, zeta)
+    d = c.upload(coeffs)
+    assert np.array_equal(c.poly_eval_dev(d, length, zeta), ev)
+    w, winf, rv, got_ev = c.open_end(c.open_begin(d, length, blind, zeta, chal))
+    assert np.array_equal(got_ev, ev)
+    comm, cinf = c.commit_end(c.commit_begin(d, length, blind))
+    c.free(d)
+    # through the trapdoor, all scalars as integers: C = (f(tau) + gs r(tau)) G and (tau - zeta) W = c C - c v G - random_v gs G
+    r_mod = pm.R_MOD
+    t, g_s, z, ch = (synth.from_mont(x.reshape(1, 4))[0] for x in (tau, gs, zeta, chal))
+    f_tau = synth.from_mont(orc.poly_eval(coeffs, tau).reshape(1, 4))[0]
+    v = synth.from_mont(ev.reshape(1, 4))[0]
+    r = synth.from_mont(blind)
+    r_at = lambda x: (r[0] + r[1] * x + r[2] * x * x) % r_mod
+    C, W = orc.point_to_ints(comm, cinf), orc.point_to_ints(w, winf)
+    assert C == pm.g1_mul((f_tau + g_s * r_at(t)) % r_mod, pm.G1_GEN)
+    random_v = synth.from_mont(rv.reshape(1, 4))[0]
+    assert random_v == ch * r_at(z) % r_mod
+    assert pm.kzg_check_with_trapdoor(C, W, v, random_v, z, ch, t, g_s)
+    c.close()
+
+
 def test_grand_product_2p23_three_scan_levels(orc):
     """2^23 rows = 4096 scan blocks: the block products themselves need two blocks and a third level.  Random rows and a random
     permutation; z on H against the oracle."""
