@@ -72,7 +72,10 @@ __device__ __forceinline__ void load_quad(const uint32_t* __restrict__ c, uint64
 // alone, 2^20 coefficients take 0.17 ms with L = 8 and 0.22 ms with L = 32, 2^22 coefficients 0.41 against 0.35 ms.
 constexpr int DIV_THREADS = 256;
 constexpr int DIV_LOG_L_SHORT = 3, DIV_LOG_L_LONG = 5;
-constexpr uint64_t DIV_LONG_FROM = 1ull << 21;
+#ifndef PLK_DIV_LONG_FROM_LOG
+#define PLK_DIV_LONG_FROM_LOG 21
+#endif
+constexpr uint64_t DIV_LONG_FROM = 1ull << PLK_DIV_LONG_FROM_LOG;
 static int div_log_l(uint64_t len) { return len < DIV_LONG_FROM ? DIV_LOG_L_SHORT : DIV_LOG_L_LONG; }
 static uint64_t div_block(uint64_t len) { return (uint64_t)DIV_THREADS << div_log_l(len); }
 
