@@ -350,6 +350,11 @@ def main():
                     "busy_ms_per_proof": round(acc_busy_ms / args.steps, 3), "achieved": round(achieved_busy / 1e12, 3), "frac": round(achieved_busy / MAD_PEAK, 4)},
         "isolated": {"note": "one commitment of 2^%d coefficients at a time, outside the timed region" % log_n, "avg_launch_ms": round(iso_launch_ms, 4),
                      "pairs": int(iso_pairs), "achieved": round(achieved_iso / 1e12, 3), "frac": round(achieved_iso / MAD_PEAK, 4)},
+        "instruction_stream": {"note": "from rocprofv3 SQ counters of a standalone 2^20-point launch (profiles/r02d_msm20_pmc_sq_a.txt), not measured in this run: "
+                                       "VALU wave-instructions per mixed addition, the fraction of the roofline a stream of that length can reach at one "
+                                       "instruction per four cycles (1360 algorithmic multiply-adds / executed instructions), and the share of the kernel's "
+                                       "cycles in which the VALU pipes issue",
+                               "valu_instructions_per_addition": 2179, "ceiling_frac": round(1360.0 / 2179.0, 4), "valu_busy": 0.95},
         "hbm": {"bound": "hbm", "achieved": round(bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else 0.0, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(bytes_per_launch / (avg_launch_ms * 1e-3) / HBM_PEAK, 4) if avg_launch_ms > 0 else 0.0, "bytes_per_pair": 96,
                 "traffic_GBps": round(traffic_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else 0.0},
