@@ -24,12 +24,24 @@ HBM_PEAK = 8.0e12
 WINDOWS = 16                # 16-bit signed windows over 254-bit scalars
 MODMUL_PER_MADD = 10        # XYZZ mixed addition: 8 M + 2 S
 MADS_PER_MODMUL = 136       # 8x8 + 8x8 + 8 multiply-adds of an 8x32-bit-limb Montgomery product (the algorithmic count)
-# HBM-side bytes of k_msm_accumulate per (point, window) entry, from rocprofv3 PMC passes over this same command
-# (FETCH_SIZE 1.419 GB + WRITE_SIZE 0.044 GB per launch of 18.64 M entries on average; profiles/r02d_bench20_pmc_*.txt;
-# the r02b pass measured 1.359 GB: the share of the gathers served by the last-level cache varies from run to run).
-# The algorithmic figure is 64 B table point + 4 B sorted entry = 68 B.
-ACC_TRAFFIC_BYTES_PER_ENTRY = 78.5
+ACC_ALGO_BYTES_PER_ENTRY = 68.0   # 64 B table point + 4 B sorted entry gathered per (pair, window)
 
+
+def profile_derived():
+    """Figures that come from rocprofv3 counter passes, not from this run: profiles/current.json, written by tools/profile_round.sh
+    together with the hash of the kernel library it profiled.  Returned with stale = True when the library loaded now is another build."""
+    import hashlib
+    from plonk_amd import hip
+    path = os.path.join(ROOT, "profiles", "current.json")
+    try:
+        with open(path) as f:
+            cur = json.load(f)
+        with open(hip.LIB_PATH, "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    except (OSError, ValueError):
+        return None
+    cur["stale"] = bool(cur.get("library_sha16") != sha)
+    return cur
 
 def _cpu_model():
     try:
@@ -98,11 +110,11 @@ def cpu_baseline(pk, inputs, tables, blinds, chal, gpu_proof, log_gates, log_gat
     }
 
 
-def ntt_stress(ctx, rank, world, local_rank, backend, log_n, reps, dist, torch):
+def ntt_stress(ctx, rank, world, local_rank, backend, log_n, reps, dist, torch, library_exchange=False):
     """Standalone coset NTT of 2^log_n points (BASELINE.json configs[4]) outside the timed region of the proof: on one GPU the
     library's transform, on N GPUs the four-step form with one all-to-all (plonk_amd/dist_ntt.py).  Inputs resident in HBM."""
     from plonk_amd import dist_ntt
-    ops = dist_ntt.HipOps(ctx, local_rank, backend=backend)
+    ops = dist_ntt.HipOps(ctx, local_rank, backend=backend, library_exchange=library_exchange)
     sn = dist_ntt.ShardedNtt(ops, rank, world, log_n, coset=5)
     m = (1 << log_n) // world
     rng = np.random.default_rng(3 + rank)
@@ -151,7 +163,9 @@ def ntt_stress(ctx, rank, world, local_rank, backend, log_n, reps, dist, torch):
         "mad_frac": round(mads / fwd_s / (MAD_PEAK * world), 4),
         "note": "algorithmic bytes 64 N (each element read and written once), algorithmic work N/2 log2 N modular products of 136 multiply-adds; "
                 "the transform is bound by the integer VALU rate, not by HBM" + ("" if world == 1 else
-                "; four-step split, coefficients cyclic over ranks, evaluations in column blocks, one all_to_all_single over RCCL"),
+                "; four-step split, coefficients cyclic over ranks, evaluations in column blocks, " +
+                ("one plk_ntt_sharded_dev call per transform: the exchange is grouped ncclSend / ncclRecv on the library's stream" if library_exchange
+                 else "one all_to_all_single over torch.distributed between the library's two halves")),
     }
 
 
@@ -192,6 +206,7 @@ def main():
     log_n = args.log_gates
     n = 1 << log_n
     n4 = 4 * n
+    library_comm = False
     t_setup = time.perf_counter()
     variables, gates = synth.synthetic_circuit(log_n, seed=args.seed)
     tables = synth.circuit_tables(variables, gates)
@@ -237,6 +252,7 @@ def main():
             agreed = torch.tensor([ok], dtype=torch.int32, device=gather_device)
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             if int(agreed.item()) == 1:
+                library_comm = True
                 collective = "ncclAllGather inside libplonk_hip (RCCL over xGMI)"
             else:                        # fall back to the gather above, still RCCL
                 if why:
@@ -339,26 +355,39 @@ def main():
     achieved_iso = iso_pairs * mads_per_pair / (iso_launch_ms * 1e-3) if iso_launch_ms > 0 else 0.0
     pk.ctx.profile_enable(False)
     bytes_per_launch = pairs_per_launch * 96.0
-    traffic_per_launch = pairs_per_launch * WINDOWS * ACC_TRAFFIC_BYTES_PER_ENTRY
+    derived = profile_derived()
+    acc_prof = (derived or {}).get("k_msm_accumulate")
+    traffic_per_launch = pairs_per_launch * WINDOWS * acc_prof["traffic_bytes_per_entry"] if acc_prof else None
+    # The object leads with the figure that fits inside ms_per_step: algorithmic multiply-adds of the whole proof over the time at
+    # least one accumulation kernel was running.  The per-launch figure (algorithmic work of one launch over its own duration, what
+    # rocprofv3 reports as the kernel's average) follows as a sub-field: two launches overlap nearly all the time, so each sees half
+    # a chip and its duration counts the shared time twice.
     roofline = {
-        "kernel": "k_msm_accumulate", "bound": "valu_int", "achieved": round(achieved / 1e12, 3), "peak": MAD_PEAK / 1e12,
-        "unit": "T mad/s (algorithmic 32-bit multiply-adds: pairs x 16 windows x 10 modmul x 136)", "frac": round(achieved / MAD_PEAK, 4),
-        "traffic": round(traffic_per_launch), "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r02d_bench20_pmc_*.txt)",
-        "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_proof": int(launches_per_proof),
-        "pairs_per_launch_avg": int(pairs_per_launch),
-        "overlap": {"note": "launches alternate between two streams and overlap; busy = time with at least one launch running",
-                    "busy_ms_per_proof": round(acc_busy_ms / args.steps, 3), "achieved": round(achieved_busy / 1e12, 3), "frac": round(achieved_busy / MAD_PEAK, 4)},
+        "kernel": "k_msm_accumulate", "bound": "valu_int", "achieved": round(achieved_busy / 1e12, 3), "peak": MAD_PEAK / 1e12,
+        "unit": "T mad/s (algorithmic 32-bit multiply-adds: pairs x 16 windows x 10 modmul x 136)", "frac": round(achieved_busy / MAD_PEAK, 4),
+        "basis": "busy time: all launches of a proof over the time at least one of them was running (HIP events on their streams)",
+        "busy_ms_per_proof": round(acc_busy_ms / args.steps, 3),
+        "traffic": round(traffic_per_launch) if traffic_per_launch is not None else None,
+        "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE of this command, profiles/current.json); algorithmic: %d" % round(pairs_per_launch * WINDOWS * ACC_ALGO_BYTES_PER_ENTRY),
+        "per_launch": {"note": "algorithmic work of one launch over its own duration; launches alternate between two streams and overlap",
+                       "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_proof": int(launches_per_proof), "pairs_per_launch_avg": int(pairs_per_launch),
+                       "achieved": round(achieved / 1e12, 3), "frac": round(achieved / MAD_PEAK, 4)},
         "isolated": {"note": "one commitment of 2^%d coefficients at a time, outside the timed region" % log_n, "avg_launch_ms": round(iso_launch_ms, 4),
                      "pairs": int(iso_pairs), "achieved": round(achieved_iso / 1e12, 3), "frac": round(achieved_iso / MAD_PEAK, 4)},
-        "instruction_stream": {"note": "from rocprofv3 SQ counters of a standalone 2^20-point launch (profiles/r02d_msm20_pmc_sq_a.txt), not measured in this run: "
-                                       "VALU wave-instructions per mixed addition, the fraction of the roofline a stream of that length can reach at one "
-                                       "instruction per four cycles (1360 algorithmic multiply-adds / executed instructions), and the share of the kernel's "
-                                       "cycles in which the VALU pipes issue",
-                               "valu_instructions_per_addition": 2179, "ceiling_frac": round(1360.0 / 2179.0, 4), "valu_busy": 0.95},
         "hbm": {"bound": "hbm", "achieved": round(bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else 0.0, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(bytes_per_launch / (avg_launch_ms * 1e-3) / HBM_PEAK, 4) if avg_launch_ms > 0 else 0.0, "bytes_per_pair": 96,
-                "traffic_GBps": round(traffic_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else 0.0},
+                "traffic_GBps": round(traffic_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 and traffic_per_launch is not None else None},
     }
+    if acc_prof:
+        roofline["instruction_stream"] = {
+            "note": "rocprofv3 SQ counters of a standalone 2^20-point launch (profiles/current.json; not measured in this run): VALU wave-instructions per "
+                    "mixed addition, the fraction of the roofline a stream of that length can reach at one instruction per four cycles (1360 "
+                    "algorithmic multiply-adds / executed instructions), the share of the kernel's cycles in which the VALU pipes issue",
+            "valu_instructions_per_addition": acc_prof["valu_instructions_per_addition"],
+            "ceiling_frac": round(1360.0 / acc_prof["valu_instructions_per_addition"], 4), "valu_busy": acc_prof["valu_busy"]}
+        roofline["profile"] = {"tag": derived.get("tag"), "library_sha16": derived.get("library_sha16"), "stale": derived["stale"]}
+    else:
+        roofline["profile"] = {"stale": True, "note": "profiles/current.json missing: traffic and instruction-stream figures not available"}
     out = {
         "metric": "prove time @2^%d gates" % log_n, "value": round(ms_per_step, 3), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
@@ -379,7 +408,7 @@ def main():
     if args.ntt_log_n:
         try:
             import torch as _torch
-            out["ntt_stress"] = ntt_stress(pk.ctx, rank, world, local_rank, args.dist_backend, args.ntt_log_n, 5, dist, _torch)
+            out["ntt_stress"] = ntt_stress(pk.ctx, rank, world, local_rank, args.dist_backend, args.ntt_log_n, 5, dist, _torch, library_exchange=library_comm)
         except Exception as e:   # the proof line above stands on its own
             out["ntt_stress"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:

@@ -224,6 +224,19 @@ int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out_xy[8], int
 int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
                            const uint64_t challenge[4], int32_t* ticket);
 int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]);
+/* plk_kzg_open_begin for `count` polynomials opened at one point with one challenge (the nine openings of src/prover.rs:295-303):
+ * coeffs_dev[k] / len[k] / blind + 12 k describe polynomial k, tickets[k] receives its ticket; each is ended with plk_kzg_open_end or
+ * plk_kzg_end_partial like any other.  Same results as `count` calls of plk_kzg_open_begin in the same order; the divisions by
+ * (X - zeta) of all polynomials run as one batch of launches before the first sort.  count <= 10; all tickets of one batch must have
+ * ended before the next batch begins. */
+int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const void* const* coeffs_dev, const uint64_t* len, const uint64_t* blind,
+                                 const uint64_t zeta[4], const uint64_t challenge[4], int32_t* tickets);
+/* Ordering of a *_begin call against later calls on the same context: the polynomial a *_begin call reads (coeffs_dev) may be
+ * overwritten by any later compute call of this context (plk_ntt_dev_enqueue in place, plk_copy_dev, plk_upload, a quotient or
+ * grand product writing into it, ...): the library orders that call behind the ticket's last read.  Two exceptions, both by
+ * contract: compute work issued while detached (plk_compute_detach) must not write what an open ticket still reads, and a
+ * plk_upload_enqueue after the first one of a batch (the batch ends with plk_kzg_submit) must not target a buffer that a *_begin
+ * call made since that first upload reads. */
 /* Tells the library that the batch of tickets begun so far is complete.  The last stage of every MSM (bucket reduction and
  * read-back) shares one stream; it is enqueued for the whole batch at once, ordered by expected completion, either here or at
  * the first *_end of the batch.  Calling this right after the last *_begin lets that stage start while the host does other work. */
@@ -250,6 +263,24 @@ int32_t plk_comm_get_unique_id(uint8_t id[128]);
 int32_t plk_comm_init(plk_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
 int32_t plk_comm_destroy(plk_ctx* ctx);
 int32_t plk_comm_all_gather_partials(plk_ctx* ctx, const uint64_t* mine, uint64_t count, uint64_t* all);
+
+/* Four-step NTT of N = 2^log_n points over the G = 1, 2, 4 or 8 ranks of the communicator, one all-to-all per transform, everything
+ * enqueued on the context's stream (no device-wide wait, no host round trip): the multi-GPU form of the ark-poly fft / ifft calls
+ * the reference makes at src/poly_utils.rs:27-28 and src/prover.rs:232-237, for transforms that are worth spreading (2^24 points and
+ * up).  Every rank passes its M = N / G elements in data_dev and a second buffer of M elements in tmp_dev.  One exchange means
+ * different layouts on the two sides (like the bit-reversed output of an in-place FFT):
+ *   coefficients  cyclic:         rank g holds c[g + G m] at m                          (input of forward, output of inverse)
+ *   evaluations   column blocks:  rank r holds X[(r M/G + k2) + M k1] at k1 M/G + k2    (output of forward, input of inverse)
+ * forward: local (coset) NTT of M points -> times h^g w_N^(g k2) -> all-to-all (grouped ncclSend / ncclRecv, one block of M / G
+ * elements per pair of ranks, each over its own xGMI link) -> G-point transforms across the received blocks; inverse: the same
+ * backwards, 1/N folded into the twiddle step and the local inverse NTT.  coset_gen as for plk_ntt (NULL: none).
+ * *result_in_tmp tells which buffer holds the result (tmp_dev whenever an exchange took place); the other one is scratch.
+ * phase 0: the whole transform (rank and world are the communicator's; the two arguments are ignored).
+ * phase 1 / 2: only this rank's work before / after the exchange, in place in data_dev, for `rank` of `world` as given and without
+ *   a communicator: for callers that move the blocks themselves (logical ranks on one device in the tests, another transport).
+ * phase 3: phase 0, with the exchange performed even when the communicator has a single rank (it sends to itself). */
+int32_t plk_ntt_sharded_dev(plk_ctx* ctx, void* data_dev, void* tmp_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen, uint32_t phase,
+                            uint32_t rank, uint32_t world, int32_t* result_in_tmp);
 
 /* ---- scheduling hint with no counterpart in the reference (which runs everything in sequence).  The library runs NTT, pointwise and
  * scan kernels ("compute" work) on the same stream as the sorting stage of its MSMs, so that a commitment sees the polynomial the

@@ -84,20 +84,43 @@ static int32_t grow(plk_ctx* ctx, hipStream_t st, uint32_t** buf, uint64_t* cap,
     return PLK_OK;
 }
 
+// One stream after another: everything enqueued on `first` so far is ordered before whatever is enqueued on `then` from now on.
+// The events come from a ring kept by the context (creating and destroying one per call cost a proof about forty pairs of
+// runtime calls on its critical path).
+int32_t order_streams(plk_ctx* ctx, hipStream_t first, hipStream_t then) {
+    if (first == then) return PLK_OK;
+    hipEvent_t& ev = ctx->order_ev[ctx->order_turn++ % plk_ctx::ORDER_EVENTS];
+    if (!ev) PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PLK_HIP(hipEventRecord(ev, first));
+    PLK_HIP(hipStreamWaitEvent(then, ev, 0));
+    return PLK_OK;
+}
+// The front work of every second job runs on the reduction stream and reads the job's polynomial there, while the calls that may
+// overwrite that polynomial afterwards (transforms in place, copies, uploads, pointwise kernels) run on the front stream.  The end of
+// the last such read is marked here, and the next compute call on the front stream waits for the mark: the ordering costs nothing
+// until somebody needs it (making the front stream wait at once would hold up the sort of the job after next).
+int32_t lane_read_mark(plk_ctx* ctx, hipStream_t lane) {
+    if (ctx->detached || lane != ctx->st_red) return PLK_OK;
+    if (!ctx->lane_read) PLK_HIP(hipEventCreateWithFlags(&ctx->lane_read, hipEventDisableTiming));
+    PLK_HIP(hipEventRecord(ctx->lane_read, lane));
+    ctx->lane_read_pending = true;
+    return PLK_OK;
+}
+int32_t compute_guard(plk_ctx* ctx) {
+    if (!ctx->lane_read_pending || ctx->stream != ctx->st_sort) return PLK_OK;   // detached compute work shares the stream of those reads
+    PLK_HIP(hipStreamWaitEvent(ctx->st_sort, ctx->lane_read, 0));
+    ctx->lane_read_pending = false;
+    return PLK_OK;
+}
+
 // orders the sort stream (the entry of the MSM pipeline) after everything already enqueued on the compute stream
 static int32_t sort_after_compute(plk_ctx* ctx, hipStream_t lane) {
     if (ctx->detached) return PLK_OK;   // the caller promised that this job's inputs do not come from the detached compute work
-    if (lane == ctx->stream) return PLK_OK;
     // The event also covers the divisions and sorts that earlier *_begin calls have put on the compute stream, which this job does
     // not need.  Waiting for them all the same is the better schedule: with an event that marks the end of the compute work only,
     // the two front streams run freely side by side, more sorting kernels share the chip with the accumulation kernels at a time,
     // and a proof of 2^20 gates takes 0.5 ms longer (measured on one box: 31.5 against 31.0 ms).
-    hipEvent_t ev;
-    PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    PLK_HIP(hipEventRecord(ev, ctx->stream));
-    PLK_HIP(hipStreamWaitEvent(lane, ev, 0));
-    PLK_HIP(hipEventDestroy(ev));
-    return PLK_OK;
+    return order_streams(ctx, ctx->stream, lane);
 }
 
 }  // namespace plk
@@ -290,6 +313,9 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     prof_collect(ctx, true);
     if (ctx->prof_base) hipEventDestroy(ctx->prof_base);
     for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->order_ev) if (e) hipEventDestroy(e);
+    if (ctx->lane_read) hipEventDestroy(ctx->lane_read);
+    hipFree(ctx->batch_dev); hipHostFree(ctx->batch_host);
     if (ctx->comm) plk_comm_destroy(ctx);
     for (auto& s : ctx->slot) slot_destroy(s);
     delete static_cast<StagePool*>(ctx->stage);
@@ -317,6 +343,7 @@ extern "C" int32_t plk_free(plk_ctx* ctx, void* dev) {
 extern "C" int32_t plk_upload(plk_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes) {
     if (!ctx || (bytes && (!dev_dst || !host_src))) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(compute_guard(ctx));
     PLK_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     return PLK_OK;
@@ -330,6 +357,10 @@ extern "C" int32_t plk_upload_enqueue(plk_ctx* ctx, void* dev_dst, const void* h
     if (!ctx || (bytes && (!dev_dst || !host_src))) return PLK_ERR_INVALID_ARG;
     if (!bytes) return PLK_OK;
     PLK_HIP(hipSetDevice(ctx->device));
+    // The transfers use the reduction stream as their copy queue.  The first one of a batch is ordered behind everything the front
+    // stream holds (sorts, divisions and compute work of earlier calls that may still read or write dev_dst); the later ones follow it
+    // without waiting for the sorts begun in between, which read other buffers (see include/plonk_hip.h).
+    if (!ctx->uploads_pending) PLK_TRY(order_streams(ctx, ctx->st_sort, ctx->st_red));
     ctx->uploads_pending = true;
     StagePool* sp = bytes >= (1u << 20) && !host_memory_is_pinned(host_src) ? stage_pool(ctx) : nullptr;
     if (sp) {
@@ -349,12 +380,7 @@ extern "C" int32_t plk_upload_enqueue(plk_ctx* ctx, void* dev_dst, const void* h
     } else {
         PLK_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->st_red));
     }
-    hipEvent_t ev;
-    PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    PLK_HIP(hipEventRecord(ev, ctx->st_red));
-    PLK_HIP(hipStreamWaitEvent(ctx->st_sort, ev, 0));
-    PLK_HIP(hipEventDestroy(ev));
-    return PLK_OK;
+    return order_streams(ctx, ctx->st_red, ctx->st_sort);
 }
 extern "C" int32_t plk_host_malloc(plk_ctx* ctx, uint64_t bytes, void** host) {
     if (!ctx || !host) return PLK_ERR_INVALID_ARG;
@@ -378,17 +404,9 @@ extern "C" int32_t plk_download(plk_ctx* ctx, void* host_dst, const void* dev_sr
 extern "C" int32_t plk_copy_dev(plk_ctx* ctx, void* dev_dst, const void* dev_src, uint64_t bytes, uint64_t total_bytes) {
     if (!ctx || !dev_dst || (bytes && !dev_src) || total_bytes < bytes) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(compute_guard(ctx));
     if (bytes) PLK_HIP(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (total_bytes > bytes) PLK_HIP(hipMemsetAsync((char*)dev_dst + bytes, 0, total_bytes - bytes, ctx->stream));
-    return PLK_OK;
-}
-// One stream after another: everything enqueued on `first` so far is ordered before whatever is enqueued on `then` from now on.
-static int32_t order_streams(plk_ctx* ctx, hipStream_t first, hipStream_t then) {
-    hipEvent_t ev;
-    PLK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    PLK_HIP(hipEventRecord(ev, first));
-    PLK_HIP(hipStreamWaitEvent(then, ev, 0));
-    PLK_HIP(hipEventDestroy(ev));
     return PLK_OK;
 }
 extern "C" int32_t plk_compute_detach(plk_ctx* ctx, int32_t on) {
@@ -402,7 +420,7 @@ extern "C" int32_t plk_compute_detach(plk_ctx* ctx, int32_t on) {
         ctx->stream = ctx->st_red;
         ctx->detached = true;
     } else {
-        if (on == 0) PLK_TRY(order_streams(ctx, ctx->st_red, ctx->st_sort));   // later calls may read what the detached work produced
+        if (on == 0) { PLK_TRY(order_streams(ctx, ctx->st_red, ctx->st_sort)); ctx->lane_read_pending = false; }   // later calls may read what the detached work produced
         ctx->stream = ctx->st_sort;
         ctx->detached = false;
     }
@@ -468,6 +486,10 @@ struct Rccl {
     int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;       // the four point-to-point symbols are optional:
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;             // without them the sharded transform is refused,
+    int (*GroupStart)() = nullptr;                                                  // the exchange of partial sums still works
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -488,6 +510,10 @@ bool rccl_open(std::string* why) {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) { *why = "librccl lacks an expected symbol"; return false; }
     g_rccl = r;
     return true;
@@ -520,10 +546,18 @@ extern "C" int32_t plk_comm_init(plk_ctx* ctx, const uint8_t id[128], uint32_t r
     void* comm = nullptr;
     const int rc = g_rccl.CommInitRank(&comm, (int)world, u, (int)rank);
     if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+    // the staging buffers first: a context whose communicator exists always has them
+    void *send = nullptr, *recv = nullptr, *host = nullptr;
+    if (hipMalloc(&send, COMM_MAX_POINTS * 128) != hipSuccess || hipMalloc(&recv, COMM_MAX_POINTS * 128 * world) != hipSuccess ||
+        hipHostMalloc(&host, COMM_MAX_POINTS * 128 * (world + 1), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(send); hipFree(recv); hipHostFree(host);
+        g_rccl.CommDestroy(comm);
+        ctx->err = "plk_comm_init: no memory for the staging buffers";
+        return PLK_ERR_ALLOC;
+    }
     ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
-    PLK_HIP(hipMalloc(&ctx->comm_send, COMM_MAX_POINTS * 128));
-    PLK_HIP(hipMalloc(&ctx->comm_recv, COMM_MAX_POINTS * 128 * world));
-    PLK_HIP(hipHostMalloc(&ctx->comm_host, COMM_MAX_POINTS * 128 * (world + 1), hipHostMallocDefault));
+    ctx->comm_send = send; ctx->comm_recv = recv; ctx->comm_host = host;
     return PLK_OK;
 }
 extern "C" int32_t plk_comm_destroy(plk_ctx* ctx) {
@@ -558,7 +592,54 @@ extern "C" int32_t plk_comm_all_gather_partials(plk_ctx* ctx, const uint64_t* mi
     return PLK_OK;
 }
 
+// ---- four-step NTT across the ranks of the communicator --------------------------------------------------------------
+// all-to-all of this rank's M elements: block r of `send` goes to rank r, block g of rank r's buffer arrives as block r of `recv`.
+// Grouped point-to-point transfers on the compute stream: xGMI links are point to point, so every pair of ranks uses its own link
+// and no ring is involved; nothing waits on the host.
+static int32_t exchange_blocks(plk_ctx* ctx, hipStream_t st, const uint32_t* send, uint32_t* recv, uint64_t block_words) {
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) { ctx->err = "librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd"; return PLK_ERR_HIP; }
+    const uint32_t world = ctx->comm_world;
+    int rc = g_rccl.GroupStart();
+    if (rc != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
+    for (uint32_t r = 0; r < world && rc == 0; ++r) {
+        rc = g_rccl.Send(send + (size_t)r * block_words, block_words / 2, RCCL_UINT64, (int)r, ctx->comm, st);
+        if (rc == 0) rc = g_rccl.Recv(recv + (size_t)r * block_words, block_words / 2, RCCL_UINT64, (int)r, ctx->comm, st);
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc != 0) return rccl_fail(ctx, "ncclSend / ncclRecv", rc);
+    if (rc_end != 0) return rccl_fail(ctx, "ncclGroupEnd", rc_end);
+    return PLK_OK;
+}
+extern "C" int32_t plk_ntt_sharded_dev(plk_ctx* ctx, void* data_dev, void* tmp_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen, uint32_t phase,
+                                       uint32_t rank, uint32_t world, int32_t* result_in_tmp) {
+    if (!ctx || !data_dev || phase > 3) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(compute_guard(ctx));
+    hipStream_t st = ctx->stream;
+    uint32_t* data = (uint32_t*)data_dev;
+    if (phase == 1 || phase == 2) {       // the halves on their own: the caller moves the blocks (logical ranks on one device, another transport)
+        if (result_in_tmp) *result_in_tmp = 0;
+        return ntt_sharded_half(ctx, st, data, log_n, inverse != 0, coset_gen, rank, world, (int)phase);
+    }
+    if (!ctx->comm) { ctx->err = "plk_ntt_sharded_dev: no communicator (plk_comm_init)"; return PLK_ERR_INVALID_ARG; }
+    if (!tmp_dev || !result_in_tmp) return PLK_ERR_INVALID_ARG;
+    rank = ctx->comm_rank; world = ctx->comm_world;
+    PLK_TRY(ntt_sharded_half(ctx, st, data, log_n, inverse != 0, coset_gen, rank, world, 1));
+    uint32_t* out = data;
+    if (world > 1 || phase == 3) {        // phase 3: the exchange also with a single rank (it sends to itself), so that one GPU exercises it
+        uint32_t log_g = 0;
+        while ((1u << log_g) < world) ++log_g;
+        const uint64_t m = 1ull << (log_n - log_g);
+        PLK_TRY(exchange_blocks(ctx, st, data, (uint32_t*)tmp_dev, m / world * 8));
+        out = (uint32_t*)tmp_dev;
+    }
+    PLK_TRY(ntt_sharded_half(ctx, st, out, log_n, inverse != 0, coset_gen, rank, world, 2));
+    *result_in_tmp = out != data ? 1 : 0;
+    return PLK_OK;
+}
+
 // ---- KZG commit ------------------------------------------------------------------------------------
+static void slot_release(plk_ctx* ctx, MsmSlot& s);
 extern "C" int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int32_t* ticket) {
     if (!ctx || !blind || !ticket || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
@@ -598,10 +679,15 @@ extern "C" int32_t plk_kzg_cancel(plk_ctx* ctx) {
     PLK_HIP(hipStreamSynchronize(ctx->st_acc[1]));
     PLK_HIP(hipStreamSynchronize(ctx->st_red));
     ctx->reduce_pending.clear();
-    for (auto& s : ctx->slot) s.busy = false;
+    for (auto& s : ctx->slot) slot_release(ctx, s);
+    ctx->batch_open = 0;
     if (ctx->detached) { ctx->stream = ctx->st_sort; ctx->detached = false; }   // everything was waited for above
     ctx->quotient_stream = nullptr;
     return PLK_OK;
+}
+static void slot_release(plk_ctx* ctx, MsmSlot& s) {
+    if (s.busy && s.in_batch && ctx->batch_open > 0) --ctx->batch_open;
+    s.busy = false; s.in_batch = false;
 }
 static int32_t ticket_slot(plk_ctx* ctx, int32_t ticket, int kind, MsmSlot** out) {
     if (!ctx || ticket < 0 || ticket >= MSM_SLOTS || !ctx->slot[ticket].busy || ctx->slot[ticket].kind != kind) {
@@ -618,7 +704,7 @@ extern "C" int32_t plk_kzg_commit_end(plk_ctx* ctx, int32_t ticket, uint64_t out
     PLK_HIP(hipSetDevice(ctx->device));
     host::pt r;
     const int32_t rc = msm_wait(ctx, *s, &r);
-    s->busy = false;
+    slot_release(ctx, *s);
     prof_collect(ctx, false);
     PLK_TRY(rc);
     host::pt_to_affine(r, out_xy, out_is_inf);
@@ -638,6 +724,17 @@ extern "C" int32_t plk_kzg_commit(plk_ctx* ctx, const uint64_t* coeffs_host, uin
 }
 
 // ---- KZG open --------------------------------------------------------------------------------------
+// hiding part of an opening, on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2 (-> hw, 16 words), random_v = r'(zeta)
+static void hiding_part(const uint64_t* blind, const uint64_t zeta[4], const uint64_t challenge[4], uint64_t random_v[4], uint32_t* hw) {
+    using namespace host;
+    const el z = el_load(zeta), ch = el_load(challenge);
+    const el r0 = mul(FR, ch, el_load(blind)), r1 = mul(FR, ch, el_load(blind + 4)), r2 = mul(FR, ch, el_load(blind + 8));
+    const el hw1 = r2, hw0 = add(FR, r1, mul(FR, z, r2));
+    const el rv = add(FR, r0, mul(FR, z, hw0));
+    memcpy(random_v, rv.v, 32);
+    memcpy(hw, hw0.v, 32);
+    memcpy(hw + 8, hw1.v, 32);
+}
 extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
                                       const uint64_t challenge[4], int32_t* ticket) {
     if (!ctx || !blind || !zeta || !challenge || !ticket || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
@@ -654,21 +751,82 @@ extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint
     const bool cyclic = ctx->cyc_world > 1;
     PLK_TRY(division_enqueue(ctx, lane, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev,
                              cyclic ? 0 : ctx->shard_first, cyclic ? len : ctx->shard_len));
+    PLK_TRY(lane_read_mark(ctx, lane));            // the division is the last reader of the caller's polynomial
     PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, lane));
-    // hiding part on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2, random_v = r'(zeta)
-    using namespace host;
-    const el z = el_load(zeta), ch = el_load(challenge);
-    const el r0 = mul(FR, ch, el_load(blind)), r1 = mul(FR, ch, el_load(blind + 4)), r2 = mul(FR, ch, el_load(blind + 8));
-    const el hw1 = r2, hw0 = add(FR, r1, mul(FR, z, r2));
-    const el rv = add(FR, r0, mul(FR, z, hw0));
-    memcpy(s.host_rv, rv.v, 32);
-    memcpy(s.blind_host, hw0.v, 32);
-    memcpy(s.blind_host + 8, hw1.v, 32);
+    s.eval_host = s.res_host; s.in_batch = false;
+    hiding_part(blind, zeta, challenge, s.host_rv, s.blind_host);
     PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 64, hipMemcpyHostToDevice, lane));
     PLK_TRY(msm_enqueue(ctx, s, s.scal_dev, len >= 2 ? len - 1 : 0, 0, 2, lane));
     s.busy = true; s.kind = 2;
     *ticket = si;
     return PLK_OK;
+}
+// All openings of a round at once (src/prover.rs:295-303: nine polynomials, one point, one challenge).  The divisions run as one
+// batch of launches at the head of the round, while the chip is idle, instead of three dependent launches per polynomial threaded
+// between the sorts and accumulations of the others; the sorts and accumulations then follow as for plk_kzg_open_begin, in the
+// order given.
+extern "C" int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const void* const* coeffs_dev, const uint64_t* len, const uint64_t* blind,
+                                            const uint64_t zeta[4], const uint64_t challenge[4], int32_t* tickets) {
+    if (!ctx || !count || !coeffs_dev || !len || !blind || !zeta || !challenge || !tickets) return PLK_ERR_INVALID_ARG;
+    if (count > (uint32_t)MSM_SLOTS) { ctx->err = "plk_kzg_open_begin_batch: more polynomials than MSM slots"; return PLK_ERR_INVALID_ARG; }
+    for (uint32_t k = 0; k < count; ++k) if (len[k] && !coeffs_dev[k]) return PLK_ERR_INVALID_ARG;
+    if (ctx->batch_open) { ctx->err = "plk_kzg_open_begin_batch: tickets of the previous batch are still open"; return PLK_ERR_INVALID_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    if (!ctx->batch_dev) {
+        PLK_HIP(hipMalloc(&ctx->batch_dev, (size_t)MSM_SLOTS * 24 * 4));
+        PLK_HIP(hipHostMalloc(&ctx->batch_host, (size_t)MSM_SLOTS * 24 * 4, hipHostMallocDefault));
+    }
+    uint32_t free_slots = 0;
+    bool idle = ctx->reduce_pending.empty();
+    for (const auto& s : ctx->slot) { free_slots += s.busy ? 0 : 1; idle = idle && !s.busy; }
+    if (free_slots < count) { ctx->err = "all MSM slots are busy: end an open ticket first"; return PLK_ERR_INVALID_ARG; }
+    // layout of the batch buffers: [count][16] hiding scalars, then [count][8] remainders
+    uint32_t* hw_dev = ctx->batch_dev;
+    uint32_t* res_dev = ctx->batch_dev + (size_t)MSM_SLOTS * 16;
+    uint32_t* hw_host = ctx->batch_host;
+    uint32_t* res_host = ctx->batch_host + (size_t)MSM_SLOTS * 16;
+    const bool cyclic = ctx->cyc_world > 1;
+    int si[MSM_SLOTS];
+    DivJob jobs[MSM_SLOTS];
+    int32_t rc = PLK_OK;
+    uint32_t taken = 0;
+    for (uint32_t k = 0; k < count && rc == PLK_OK; ++k) {
+        rc = msm_acquire_slot(ctx, &si[k]);
+        if (rc != PLK_OK) break;
+        MsmSlot& s = ctx->slot[si[k]];
+        s.busy = true; s.kind = 2; s.in_batch = true;
+        ++taken; ++ctx->batch_open;
+        rc = grow(ctx, ctx->st_sort, &s.scal_dev, &s.scal_cap, (len[k] + 1) * 8);
+        if (rc == PLK_OK) rc = grow(ctx, ctx->st_sort, &s.chain_dev, &s.chain_cap, division_work_words(len[k]));
+        jobs[k].coeffs = (const uint32_t*)coeffs_dev[k]; jobs[k].len = len[k];
+        jobs[k].q_out = s.scal_dev; jobs[k].h0_out = res_dev + 8 * k; jobs[k].work = s.chain_dev;
+        jobs[k].q_first = cyclic ? 0 : ctx->shard_first; jobs[k].q_count = cyclic ? len[k] : ctx->shard_len;
+        hiding_part(blind + 12 * k, zeta, challenge, s.host_rv, hw_host + 16 * k);
+        s.eval_host = res_host + 8 * k;
+    }
+    // the divisions go to the front stream itself: the first sort follows them there, the second front stream waits for them below
+    hipStream_t st = ctx->st_sort;
+    if (rc == PLK_OK && !ctx->detached) rc = order_streams(ctx, ctx->stream, st);
+    if (rc == PLK_OK) rc = division_enqueue_batch(ctx, st, count, jobs, zeta, challenge);
+    if (rc == PLK_OK && hipMemcpyAsync(res_host, res_dev, (size_t)count * 32, hipMemcpyDeviceToHost, st) != hipSuccess) rc = PLK_ERR_HIP;
+    if (rc == PLK_OK && hipMemcpyAsync(hw_dev, hw_host, (size_t)count * 64, hipMemcpyHostToDevice, st) != hipSuccess) rc = PLK_ERR_HIP;
+    for (uint32_t k = 0; k < count && rc == PLK_OK; ++k) {
+        MsmSlot& s = ctx->slot[si[k]];
+        hipStream_t lane = front_lane(ctx);
+        rc = sort_after_compute(ctx, lane);   // the second front stream waits for the divisions (and the sorts before this one)
+        if (rc == PLK_OK) rc = msm_enqueue(ctx, s, s.scal_dev, len[k] >= 2 ? len[k] - 1 : 0, 0, 2, lane, (idle && k == 0) ? 1 : 0, hw_dev + 16 * k);
+        tickets[k] = si[k];
+    }
+    if (rc != PLK_OK) {   // what was enqueued runs to completion on buffers that stay valid; the slots are handed back
+        (void)hipStreamSynchronize(ctx->st_sort); (void)hipStreamSynchronize(ctx->st_red);
+        (void)hipStreamSynchronize(ctx->st_acc[0]); (void)hipStreamSynchronize(ctx->st_acc[1]);
+        for (uint32_t k = 0; k < taken; ++k) {
+            auto& rp = ctx->reduce_pending;
+            rp.erase(std::remove(rp.begin(), rp.end(), si[k]), rp.end());
+            slot_release(ctx, ctx->slot[si[k]]);
+        }
+    }
+    return rc;
 }
 extern "C" int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]) {
     MsmSlot* s;
@@ -677,12 +835,12 @@ extern "C" int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[
     PLK_HIP(hipSetDevice(ctx->device));
     host::pt r;
     const int32_t rc = msm_wait(ctx, *s, &r);
-    s->busy = false;
+    slot_release(ctx, *s);
     prof_collect(ctx, false);
     PLK_TRY(rc);
     host::pt_to_affine(r, w_xy, w_is_inf);
     memcpy(random_v, s->host_rv, 32);
-    memcpy(eval, s->res_host, 32);
+    memcpy(eval, s->eval_host, 32);
     return PLK_OK;
 }
 extern "C" int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]) {
@@ -691,13 +849,13 @@ extern "C" int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t ou
     PLK_HIP(hipSetDevice(ctx->device));
     host::pt r;
     const int32_t rc = msm_wait(ctx, *s, &r);
-    s->busy = false;
+    slot_release(ctx, *s);
     prof_collect(ctx, false);
     PLK_TRY(rc);
     host::pt_store(r, out_xyzz);
     if (s->kind == 2) {
         if (random_v) memcpy(random_v, s->host_rv, 32);
-        if (eval) memcpy(eval, s->res_host, 32);
+        if (eval) memcpy(eval, s->eval_host, 32);
     }
     return PLK_OK;
 }

@@ -76,6 +76,8 @@ struct MsmSlot {
     int acc_stream = 0;                // which of the two accumulation streams runs it
     uint32_t acc_blocks = 0;
     uint64_t host_rv[4], host_chal[4]; // opening: values finished on the host
+    const uint32_t* eval_host = nullptr;   // opening: where the remainder f(zeta) arrives (res_host, or the batch's pinned buffer)
+    bool in_batch = false;             // begun by plk_kzg_open_begin_batch
 };
 
 }  // namespace plk
@@ -89,6 +91,18 @@ struct plk_ctx {
     // latency-bound stages of their neighbours fill in beside them.
     hipStream_t st_sort = nullptr, st_acc[2] = {nullptr, nullptr}, st_red = nullptr;
     unsigned lane_turn = 0;            // front_lane(): whose turn it is
+    // Events that order one stream behind another (order_streams): a ring, created on first use and re-recorded in turn.  A wait
+    // refers to the record that was current when it was enqueued, so a slot may be recorded again while earlier waits are pending.
+    static constexpr int ORDER_EVENTS = 32;
+    hipEvent_t order_ev[ORDER_EVENTS] = {};
+    unsigned order_turn = 0;
+    // A *_begin whose front work went to the second front stream (st_red) reads its polynomial there.  lane_read marks the end of
+    // the last such read; compute work on the first front stream that may overwrite the polynomial waits for it (compute_guard).
+    hipEvent_t lane_read = nullptr;
+    bool lane_read_pending = false;
+    int batch_open = 0;                // tickets of the last plk_kzg_open_begin_batch that have not ended yet
+    uint32_t* batch_dev = nullptr;     // per member of a batch of openings: 16 words of hiding scalars, 8 words of remainder
+    uint32_t* batch_host = nullptr;    // pinned, same layout
     bool uploads_pending = false;      // plk_upload_enqueue since the last plk_kzg_submit: transfers queue on st_red, sorts keep off it
     bool detached = false;             // plk_compute_detach: `stream` is st_red for the time being, so compute work runs beside the sorts on st_sort
     uint64_t acc_load[2] = {0, 0};     // entries queued on each accumulation stream since the device was last idle
@@ -162,6 +176,11 @@ void prof_end(plk_ctx* ctx, hipStream_t s);
 void prof_collect(plk_ctx* ctx, bool wait);
 
 int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes);
+// everything enqueued on `first` so far is ordered before whatever is enqueued on `then` from now on
+int32_t order_streams(plk_ctx* ctx, hipStream_t first, hipStream_t then);
+// records the end of a polynomial read on the second front stream / orders the compute stream behind the last such read
+int32_t lane_read_mark(plk_ctx* ctx, hipStream_t lane);
+int32_t compute_guard(plk_ctx* ctx);
 
 // Issue priority of the short kernels that run beside the accumulation kernel.
 #ifndef PLK_SIDE_PRIO_LEVEL

@@ -595,12 +595,13 @@ hipStream_t front_lane(plk_ctx* ctx) {
 }
 // Enqueues one MSM: main segment (device scalars over powers_of_g) plus, when n_blind > 0 and this shard holds the gamma powers,
 // n_blind scalars (already in slot.blind_dev) over powers_of_gamma_g.  The sort goes to `lane` (st_sort when null).
-int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind, hipStream_t lane) {
+int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind, hipStream_t lane, int idle_hint,
+                    const uint32_t* blind_dev) {
     if (!ctx->tables) { ctx->err = "no SRS loaded"; return PLK_ERR_INVALID_ARG; }
     if (base_offset + k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
     MsmSegs segs;
     clip_to_shard(ctx, scalars_dev, k, base_offset, &segs.s[0]);
-    segs.s[1].scalars = s.blind_dev;
+    segs.s[1].scalars = blind_dev ? blind_dev : s.blind_dev;
     segs.s[1].count = ctx->has_gamma ? n_blind : 0;
     segs.s[1].table_off = (uint32_t)ctx->shard_len;
     segs.s[1].world = 1; segs.s[1].rank = 0; segs.s[1].log_block = 0; segs.s[1].origin = 0;
@@ -618,6 +619,7 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
     hipStream_t st = lane ? lane : ctx->st_sort;
     bool idle = ctx->reduce_pending.empty();   // nothing of this context is running or queued on the device
     for (const auto& other : ctx->slot) idle = idle && (!other.busy || &other == &s);
+    if (idle_hint >= 0) idle = idle_hint != 0;   // a batch marks all its slots busy before it enqueues the first
     prof_begin(ctx, st, "msm_sort");
     uint32_t* digits = s.entries + s.entries_cap;      // 16 two-byte codes per scalar, at most entries_cap of them
     {
@@ -640,6 +642,7 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
         const uint32_t ch = (segs.total + nb - 1) / nb;
         uint32_t* part_start = s.totals;               // SORT_PARTS + 1 words (the buffer holds MSM_BUCKETS)
         hipLaunchKernelGGL(k_sort_digits_count, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts);
+        PLK_TRY(lane_read_mark(ctx, st));          // the last reader of the caller's scalars
         hipLaunchKernelGGL(k_sort_partition, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts, nb, part_start, (uint32_t)ctx->table_stride, records);
         if (fast) hipLaunchKernelGGL(k_sort_buckets<1024>, dim3(SORT_PARTS), dim3(1024), 0, st, records, part_start, s.bucket_start, s.entries);
         else hipLaunchKernelGGL(k_sort_buckets<SORT_THREADS>, dim3(SORT_PARTS), dim3(SORT_THREADS), 0, st, records, part_start, s.bucket_start, s.entries);

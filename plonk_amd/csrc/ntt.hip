@@ -12,6 +12,7 @@
 #include "common.cuh"
 #include "host_math.hpp"
 #include "kernels.h"
+#include <mutex>
 
 namespace plk {
 
@@ -567,16 +568,26 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
                 left -= q;
             }
             const dim3 grid((uint32_t)(n / NTT8_TILE)), block(NTT8_THREADS);
-            static const bool lds_allowed = [] {   // more than the 64 KB a kernel may take without asking
-                bool ok = true;
-                auto allow = [&](const void* f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NTT8_LDS_BYTES) == hipSuccess; };
-                allow(reinterpret_cast<const void*>(k_ntt_pass8<false, true, false>));
-                allow(reinterpret_cast<const void*>(k_ntt_pass8<false, false, false>));
-                allow(reinterpret_cast<const void*>(k_ntt_pass8<true, false, true>));
-                allow(reinterpret_cast<const void*>(k_ntt_pass8<false, false, true>));
-                allow(reinterpret_cast<const void*>(k_ntt_pass8<true, false, false>));
-                return ok;
-            }();
+            // more than the 64 KB a kernel may take without asking: asked for once per device (function attributes belong to the device
+            // that is current when they are set)
+            static std::mutex lds_mutex;
+            static bool lds_asked[64] = {}, lds_granted[64] = {};
+            bool lds_allowed;
+            {
+                std::lock_guard<std::mutex> lock(lds_mutex);
+                const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+                if (!lds_asked[dev]) {
+                    bool ok = true;
+                    auto allow = [&](const void* f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NTT8_LDS_BYTES) == hipSuccess; };
+                    allow(reinterpret_cast<const void*>(k_ntt_pass8<false, true, false>));
+                    allow(reinterpret_cast<const void*>(k_ntt_pass8<false, false, false>));
+                    allow(reinterpret_cast<const void*>(k_ntt_pass8<true, false, true>));
+                    allow(reinterpret_cast<const void*>(k_ntt_pass8<false, false, true>));
+                    allow(reinterpret_cast<const void*>(k_ntt_pass8<true, false, false>));
+                    lds_asked[dev] = true; lds_granted[dev] = ok;
+                }
+                lds_allowed = lds_granted[dev];
+            }
             if (!lds_allowed) { ctx->err = "k_ntt_pass8: 78 KB of LDS refused"; return PLK_ERR_HIP; }
             const uint32_t* tw_next = nullptr;
             if (!last && log_n <= NTT_TABLE_MAX_LOG_N) PLK_TRY(pass_twiddles(ctx, st, W, log_n, inverse, p, lr[p + 1], lns[p] + lr[p], &tw_next));
@@ -603,6 +614,61 @@ int32_t ntt_run(plk_ctx* ctx, hipStream_t st, uint32_t* data, uint32_t log_n, bo
     return PLK_OK;
 }
 
+static int32_t cross_enqueue(plk_ctx* ctx, hipStream_t st, uint32_t* d, uint32_t log_g, uint64_t cols, bool inverse) {
+    if (log_g == 0 || cols == 0) return PLK_OK;
+    const uint32_t* W;
+    PLK_TRY(ntt_twiddles(ctx, log_g, &W));
+    const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
+    prof_begin(ctx, st, "ntt");
+    switch (log_g) {
+        case 1: hipLaunchKernelGGL(k_ntt_cross<1>, grid, block, 0, st, d, cols, W, inverse ? 1 : 0); break;
+        case 2: hipLaunchKernelGGL(k_ntt_cross<2>, grid, block, 0, st, d, cols, W, inverse ? 1 : 0); break;
+        default: hipLaunchKernelGGL(k_ntt_cross<3>, grid, block, 0, st, d, cols, W, inverse ? 1 : 0); break;
+    }
+    prof_end(ctx, st);
+    PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+
+// One half of the four-step transform of N = 2^log_n points over `world` ranks (see plk_ntt_sharded_dev in include/plonk_hip.h) on
+// this rank's M = N / world elements.  Coefficients are cyclic over the ranks (rank g holds c[g + G m]), evaluations sit in column
+// blocks (rank r holds X[(r M/G + k2) + M k1] at k1 M/G + k2).  With i = g + G m and k = k2 + M k1:
+//   X[k2 + M k1] = sum_g w_G^(g k1) [ h^g w_N^(g k2) sum_m c_g[m] (h^G)^m w_M^(m k2) ]
+// forward, before the exchange: local (coset) transform with generator h^G, then times h^g (w_N^g)^k2; after it: G-point
+// transforms across the received blocks.  Inverse: the same backwards with inverse roots, 1/G on the twiddle step, 1/M on the
+// local inverse transform.
+int32_t ntt_sharded_half(plk_ctx* ctx, hipStream_t st, uint32_t* buf, uint32_t log_n, bool inverse, const uint64_t* coset_gen, uint32_t rank, uint32_t world,
+                         int half) {
+    uint32_t log_g = 0;
+    while ((1u << log_g) < world) ++log_g;
+    if ((1u << log_g) != world || world > 8 || rank >= world) { ctx->err = "sharded NTT: 1, 2, 4 or 8 ranks"; return PLK_ERR_INVALID_ARG; }
+    if (log_n < 2 * log_g + 1 || log_n - log_g > 27) { ctx->err = "sharded NTT: transform too small or too large for this many ranks"; return PLK_ERR_INVALID_ARG; }
+    const uint32_t log_m = log_n - log_g;
+    const uint64_t m = 1ull << log_m;
+    using namespace host;
+    const el h = coset_gen ? el_load(coset_gen) : one(FR);
+    if (coset_gen && is_zero(h)) { ctx->err = "coset generator is zero"; return PLK_ERR_INVERSE_OF_ZERO; }
+    auto pow_u = [](el b, uint64_t e) { el r = one(FR); while (e) { if (e & 1) r = mul(FR, r, b); b = mul(FR, b, b); e >>= 1; } return r; };
+    const el local = pow_u(h, world);                       // generator of the local coset transform: h^G
+    const uint64_t* local_gen = coset_gen ? local.v : nullptr;
+    const el w_n = root_of_unity(log_n);
+    const bool trivial = !coset_gen && rank == 0;
+    if (!inverse) {
+        if (half == 1) {
+            PLK_TRY(ntt_run(ctx, st, buf, log_m, false, local_gen));
+            if (world > 1 && !trivial) PLK_TRY(scale_powers(ctx, st, buf, m, pow_u(w_n, rank), pow_u(h, rank)));
+            return PLK_OK;
+        }
+        return cross_enqueue(ctx, st, buf, log_g, m / world, false);
+    }
+    if (half == 1) return cross_enqueue(ctx, st, buf, log_g, m / world, true);
+    if (world > 1) {
+        const el base = mul(FR, inv(FR, from_u64(FR, world)), inv(FR, pow_u(h, rank)));
+        PLK_TRY(scale_powers(ctx, st, buf, m, inv(FR, pow_u(w_n, rank)), base));
+    }
+    return ntt_run(ctx, st, buf, log_m, true, local_gen);
+}
+
 }  // namespace plk
 
 using namespace plk;
@@ -610,6 +676,7 @@ using namespace plk;
 extern "C" int32_t plk_ntt_dev_enqueue(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen) {
     if (!ctx || !data_dev) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(compute_guard(ctx));
     return ntt_run(ctx, ctx->stream, (uint32_t*)data_dev, log_n, inverse != 0, coset_gen);
 }
 extern "C" int32_t plk_ntt_dev(plk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, const uint64_t* coset_gen) {
@@ -633,6 +700,7 @@ extern "C" int32_t plk_scale_powers_dev(plk_ctx* ctx, void* data_dev, uint64_t n
     if (!ctx || !base || !ratio || (n && !data_dev)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     if (n == 0) return PLK_OK;
+    PLK_TRY(compute_guard(ctx));
     prof_begin(ctx, ctx->stream, "pointwise");
     const int32_t rc = scale_powers(ctx, ctx->stream, (uint32_t*)data_dev, n, host::el_load(ratio), host::el_load(base));
     prof_end(ctx, ctx->stream);
@@ -642,17 +710,6 @@ extern "C" int32_t plk_ntt_cross_dev(plk_ctx* ctx, void* data_dev, uint32_t log_
     if (!ctx || !data_dev || log_g > 3) return PLK_ERR_INVALID_ARG;   // at most 8 row blocks (GPUs of one node)
     PLK_HIP(hipSetDevice(ctx->device));
     if (log_g == 0 || cols == 0) return PLK_OK;
-    const uint32_t* W;
-    PLK_TRY(ntt_twiddles(ctx, log_g, &W));
-    const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
-    uint32_t* d = (uint32_t*)data_dev;
-    prof_begin(ctx, ctx->stream, "ntt");
-    switch (log_g) {
-        case 1: hipLaunchKernelGGL(k_ntt_cross<1>, grid, block, 0, ctx->stream, d, cols, W, inverse ? 1 : 0); break;
-        case 2: hipLaunchKernelGGL(k_ntt_cross<2>, grid, block, 0, ctx->stream, d, cols, W, inverse ? 1 : 0); break;
-        default: hipLaunchKernelGGL(k_ntt_cross<3>, grid, block, 0, ctx->stream, d, cols, W, inverse ? 1 : 0); break;
-    }
-    prof_end(ctx, ctx->stream);
-    PLK_HIP(hipGetLastError());
-    return PLK_OK;
+    PLK_TRY(compute_guard(ctx));
+    return cross_enqueue(ctx, ctx->stream, (uint32_t*)data_dev, log_g, cols, inverse != 0);
 }

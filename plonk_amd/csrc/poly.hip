@@ -123,25 +123,49 @@ __device__ __forceinline__ fe div_pow2(fe x, int squarings) {
     return x;
 }
 
+// The three kernels take a batch: blockIdx.y (plus member0) selects the polynomial, so that the nine openings of a round
+// (src/prover.rs:295-303: all nine polynomials are known once zeta is) cost three to five launches instead of twenty-seven.
+struct DivBatch {
+    const uint32_t* c[DIV_BATCH_MAX];
+    uint64_t len[DIV_BATCH_MAX];
+    uint32_t* A[DIV_BATCH_MAX];            // block sums
+    uint32_t* carry[DIV_BATCH_MAX];
+    uint32_t* q_out[DIV_BATCH_MAX];
+    uint32_t* h0_out[DIV_BATCH_MAX];
+    uint32_t nb[DIV_BATCH_MAX];            // blocks of the member
+    uint32_t first_block[DIV_BATCH_MAX];   // k_div_apply walks blocks first_block .. first_block + apply_blocks - 1
+    uint32_t apply_blocks[DIV_BATCH_MAX];
+    uint32_t log_block[DIV_BATCH_MAX];     // log2 of the coefficients per block
+    W8 zeta, scale;
+    uint32_t cyc_world, cyc_rank, cyc_log_block;
+};
 template <int LOG_L>
-__global__ void __launch_bounds__(DIV_THREADS) k_div_sums(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, uint32_t* __restrict__ A) {
+__global__ void __launch_bounds__(DIV_THREADS) k_div_sums(DivBatch db, uint32_t member0) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
-    const fe z = to_rp(fe_of(zeta));
+    const uint32_t mb = member0 + blockIdx.y;
+    if (blockIdx.x >= db.nb[mb]) return;
+    const uint32_t* __restrict__ c = db.c[mb];
+    const uint64_t len = db.len[mb];
+    const fe z = to_rp(fe_of(db.zeta));
     fe s = div_local_sum<LOG_L>(c, ((uint64_t)blockIdx.x * DIV_THREADS + threadIdx.x) << LOG_L, len, z);
     norm(s);
     const fe tot = div_block_suffix_scan(s, div_pow2(z, LOG_L), lds);   // thread 0 ends up with the whole block
-    if (threadIdx.x == 0) st_lazy(A + 8ull * blockIdx.x, tot);
+    if (threadIdx.x == 0) st_lazy(db.A[mb] + 8ull * blockIdx.x, tot);
 }
-// carry[b] = h at the first coefficient of block b + 1 (zero for the last block); h0 = h_0, canonical.  One workgroup.
-__global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __restrict__ A, uint32_t nb, W8 zeta, int log_block, uint32_t* __restrict__ carry,
-                                                             uint32_t* __restrict__ h0_out) {
+// carry[b] = h at the first coefficient of block b + 1 (zero for the last block); h0 = h_0, canonical.  One workgroup per polynomial.
+__global__ void __launch_bounds__(DIV_THREADS) k_div_carries(DivBatch db) {
     PLK_SIDE_PRIO();
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     __shared__ uint32_t tops[DIV_THREADS * 9];
+    const uint32_t mb = blockIdx.x;
+    const uint32_t* __restrict__ A = db.A[mb];
+    uint32_t* __restrict__ carry = db.carry[mb];
+    uint32_t* __restrict__ h0_out = db.h0_out[mb];
+    const uint32_t nb = db.nb[mb];
     const uint32_t t = threadIdx.x;
     const uint32_t m = (nb + DIV_THREADS - 1) / DIV_THREADS;            // blocks per thread
-    const fe ze = div_pow2(to_rp(fe_of(zeta)), log_block);              // z^E
+    const fe ze = div_pow2(to_rp(fe_of(db.zeta)), (int)db.log_block[mb]);   // z^E
     // weight between the chunks of neighbouring threads: ze^m
     fe wm = fe_const(FrP::ONE);
     for (uint32_t k = 0; k < m; ++k) wm = mul<FrP>(wm, ze);
@@ -173,14 +197,19 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_carries(const uint32_t* __r
 }
 // q_out[i - 1] = scale * h_i for i >= 1
 template <int LOG_L>
-__global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __restrict__ c, uint64_t len, W8 zeta, const uint32_t* __restrict__ carry,
-                                                           uint32_t* __restrict__ q_out, W8 scale, uint32_t first_block, uint32_t cyc_world, uint32_t cyc_rank,
-                                                           uint32_t cyc_log_block) {
+__global__ void __launch_bounds__(DIV_THREADS) k_div_apply(DivBatch db, uint32_t member0) {
     PLK_SIDE_PRIO();
     constexpr uint64_t BLOCK = (uint64_t)DIV_THREADS << LOG_L;
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     __shared__ uint32_t heads[DIV_THREADS * 9];
-    const uint32_t t = threadIdx.x, blk = first_block + blockIdx.x;
+    const uint32_t mb = member0 + blockIdx.y;
+    if (blockIdx.x >= db.apply_blocks[mb]) return;
+    const uint32_t* __restrict__ c = db.c[mb];
+    const uint32_t* __restrict__ carry = db.carry[mb];
+    uint32_t* __restrict__ q_out = db.q_out[mb];
+    const uint64_t len = db.len[mb];
+    const uint32_t cyc_world = db.cyc_world, cyc_rank = db.cyc_rank, cyc_log_block = db.cyc_log_block;
+    const uint32_t t = threadIdx.x, blk = db.first_block[mb] + blockIdx.x;
     if (cyc_world > 1) {
         // block-cyclic shard: q_out[k] is only used for the SRS points k this rank holds (block k >> log_block congruent to rank);
         // a workgroup whose coefficients (k = i - 1) touch none of them has nothing to write
@@ -190,7 +219,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __res
         for (uint64_t b = b_lo; !need && b <= b_hi; ++b) need = b % cyc_world == cyc_rank;
         if (!need) return;
     }
-    const fe z = to_rp(fe_of(zeta));
+    const fe z = to_rp(fe_of(db.zeta));
     const fe zl = div_pow2(z, LOG_L);
     const uint64_t lo = (uint64_t)blk * BLOCK + ((uint64_t)t << LOG_L);
     const fe cin = ld_fe(carry + 8ull * blk);
@@ -207,7 +236,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(const uint32_t* __res
 #pragma unroll
         for (int i = 0; i < 9; ++i) h.v[i] = heads[(t + 1) * 9 + i];
     }
-    const fe sc = to_rp(fe_of(scale));
+    const fe sc = to_rp(fe_of(db.scale));
 #pragma unroll 1
     for (int q = (1 << LOG_L) / 4 - 1; q >= 0; --q) {
         fe v[4];
@@ -226,36 +255,59 @@ uint64_t division_work_words(uint64_t len) {
     const uint64_t block = div_block(len), nb = (len + block - 1) / block;
     return 2 * (nb + 1) * 8 + 64;
 }
-int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
-                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work, uint64_t q_first, uint64_t q_count) {
-    const uint32_t cw = ctx->cyc_world, cr = ctx->cyc_rank, cl = ctx->cyc_log_block;
-    if (len == 0) {
-        if (h0_out) PLK_HIP(hipMemsetAsync(h0_out, 0, 32, st));
-        return PLK_OK;
-    }
-    const bool is_short = div_log_l(len) == DIV_LOG_L_SHORT;
-    const uint64_t block = div_block(len);
-    const uint32_t nb = (uint32_t)((len + block - 1) / block);
-    uint32_t* A = work;
-    uint32_t* carry = work + (size_t)(nb + 1) * 8;
-    const W8 z = w8_of(zeta);
-    prof_begin(ctx, st, "division");
-    if (is_short) hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_SHORT>, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, A);
-    else hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_LONG>, dim3(nb), dim3(DIV_THREADS), 0, st, coeffs, len, z, A);
-    hipLaunchKernelGGL(k_div_carries, dim3(1), dim3(DIV_THREADS), 0, st, A, nb, z, 8 + div_log_l(len), carry, h0_out);
-    if (q_out && len > 1 && q_count > 0) {
-        // q_out[k] comes from coefficient k + 1: only the blocks that hold coefficients q_first + 1 .. q_first + q_count are walked
-        const uint64_t hi = std::min<uint64_t>(q_first + q_count, len - 1);
-        if (q_first < hi) {
-            const uint32_t b0 = (uint32_t)((q_first + 1) / block), b1 = (uint32_t)(hi / block);
-            const W8 sc = w8_of(scale ? scale : host::FR.one);
-            if (is_short) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_SHORT>, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, sc, b0, cw, cr, cl);
-            else hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_LONG>, dim3(b1 - b0 + 1), dim3(DIV_THREADS), 0, st, coeffs, len, z, carry, q_out, sc, b0, cw, cr, cl);
+// Members are handed over in any order; the launches take the short-block ones first (blockIdx.y of the two templated kernels
+// counts inside its class).  A member of length zero gets h_0 = 0 from the carry kernel and nothing else.
+int32_t division_enqueue_batch(plk_ctx* ctx, hipStream_t st, uint32_t count, const DivJob* jobs, const uint64_t zeta[4], const uint64_t scale[4]) {
+    if (count == 0) return PLK_OK;
+    if (count > (uint32_t)DIV_BATCH_MAX) { ctx->err = "division batch too long"; return PLK_ERR_INVALID_ARG; }
+    DivBatch db;
+    memset(&db, 0, sizeof(db));
+    db.zeta = w8_of(zeta);
+    db.scale = w8_of(scale ? scale : host::FR.one);
+    db.cyc_world = ctx->cyc_world; db.cyc_rank = ctx->cyc_rank; db.cyc_log_block = ctx->cyc_log_block;
+    uint32_t n_short = 0, n = 0, max_nb[2] = {0, 0}, max_apply[2] = {0, 0};
+    for (int cls = 0; cls < 2; ++cls) {
+        for (uint32_t k = 0; k < count; ++k) {
+            const DivJob& j = jobs[k];
+            const bool is_short = div_log_l(j.len) == DIV_LOG_L_SHORT;
+            if (is_short != (cls == 0)) continue;
+            const uint64_t block = div_block(j.len);
+            const uint32_t nb = (uint32_t)((j.len + block - 1) / block);
+            db.c[n] = j.coeffs; db.len[n] = j.len; db.nb[n] = nb;
+            db.A[n] = j.work; db.carry[n] = j.work + (size_t)(nb + 1) * 8;
+            db.q_out[n] = j.q_out; db.h0_out[n] = j.h0_out;
+            db.log_block[n] = 8 + (uint32_t)div_log_l(j.len);
+            db.first_block[n] = 0; db.apply_blocks[n] = 0;
+            if (j.q_out && j.len > 1 && j.q_count > 0) {
+                // q_out[k] comes from coefficient k + 1: only the blocks that hold coefficients q_first + 1 .. q_first + q_count are walked
+                const uint64_t hi = std::min<uint64_t>(j.q_first + j.q_count, j.len - 1);
+                if (j.q_first < hi) {
+                    const uint32_t b0 = (uint32_t)((j.q_first + 1) / block), b1 = (uint32_t)(hi / block);
+                    db.first_block[n] = b0; db.apply_blocks[n] = b1 - b0 + 1;
+                }
+            }
+            max_nb[cls] = std::max(max_nb[cls], nb);
+            max_apply[cls] = std::max(max_apply[cls], db.apply_blocks[n]);
+            ++n;
         }
+        if (cls == 0) n_short = n;
     }
+    const uint32_t n_long = n - n_short;
+    prof_begin(ctx, st, "division");
+    if (n_short && max_nb[0]) hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_SHORT>, dim3(max_nb[0], n_short), dim3(DIV_THREADS), 0, st, db, 0u);
+    if (n_long && max_nb[1]) hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_LONG>, dim3(max_nb[1], n_long), dim3(DIV_THREADS), 0, st, db, n_short);
+    hipLaunchKernelGGL(k_div_carries, dim3(n), dim3(DIV_THREADS), 0, st, db);
+    if (n_short && max_apply[0]) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_SHORT>, dim3(max_apply[0], n_short), dim3(DIV_THREADS), 0, st, db, 0u);
+    if (n_long && max_apply[1]) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_LONG>, dim3(max_apply[1], n_long), dim3(DIV_THREADS), 0, st, db, n_short);
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
+}
+int32_t division_enqueue(plk_ctx* ctx, hipStream_t st, const uint32_t* coeffs, uint64_t len, const uint64_t zeta[4], const uint64_t scale[4],
+                         uint32_t* q_out, uint32_t* h0_out, uint32_t* work, uint64_t q_first, uint64_t q_count) {
+    DivJob j;
+    j.coeffs = coeffs; j.len = len; j.q_out = q_out; j.h0_out = h0_out; j.work = work; j.q_first = q_first; j.q_count = q_count;
+    return division_enqueue_batch(ctx, st, 1, &j, zeta, scale);
 }
 
 // ------------------------------------------------------------------------------------------ grand product
@@ -622,6 +674,7 @@ extern "C" int32_t plk_poly_eval_dev_static(plk_ctx* ctx, const void* coeffs_dev
     if (!work) { ctx->err = "plk_poly_eval_dev_static: static scratch of this device was not set up"; return PLK_ERR_HIP; }
     if (division_work_words(len) > EVAL_STATIC_WORDS) { ctx->err = "plk_poly_eval_dev_static: work area exceeds the static scratch"; return PLK_ERR_INVALID_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(compute_guard(ctx));                 // a stream wait at most: nothing is allocated
     const int profiling = ctx->profiling;
     ctx->profiling = 0;                       // profiling brackets create events: not on this path
     const int32_t rc = division_enqueue(ctx, ctx->stream, (const uint32_t*)coeffs_dev, len, x, nullptr, nullptr, (uint32_t*)out_dev, work, 0, 0);
@@ -660,6 +713,7 @@ static int32_t grand_product(plk_ctx* ctx, const void* witness_flat_dev, const v
     if (!z_coeffs_out_dev && (wait || !z_vals_out_dev)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
+    PLK_TRY(compute_guard(ctx));
     hipStream_t st = ctx->stream;
     // scratch: num[n], den[n], scan work (2 * n/1024 + slack), all 8-word elements
     const uint64_t work_elems = 2 * (n / 1024 + 64);
@@ -720,6 +774,7 @@ static int32_t quotient_enqueue(plk_ctx* ctx, const void* a, const void* b, cons
     if (pi_count && (!alpha || !pi_rows_host || !pi_values_host)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
+    PLK_TRY(compute_guard(ctx));
     hipStream_t st = ctx->stream;
     uint32_t* t = (uint32_t*)t_out_dev;
     // public inputs: one entry per distinct row, the last assignment wins (src/circuit.rs:432 assigns, it does not add)
@@ -822,6 +877,7 @@ extern "C" int32_t plk_interpolate_permutation_dev(plk_ctx* ctx, const void* sig
         return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n4 = 1ull << log_n4;
+    PLK_TRY(compute_guard(ctx));
     hipStream_t st = ctx->stream;
     const uint32_t* W;
     PLK_TRY(ntt_twiddles(ctx, log_n4, &W));
@@ -871,6 +927,7 @@ extern "C" int32_t plk_quotient_coset_dev(plk_ctx* ctx, const void* a, const voi
         return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n, n4 = 4 * n;
+    PLK_TRY(compute_guard(ctx));
     hipStream_t st = ctx->stream;
     host::el g = coset_gen ? host::el_load(coset_gen) : host::from_u64(host::FR, 5);
     // 1 / (g^n w_4^i - 1), i < 4

@@ -15,6 +15,11 @@ inverse: the same steps backwards with inverse roots; 1/G rides on step 2, 1/M o
 
 `ops` supplies the local work on opaque buffers: HipOps (libplonk_hip through the C ABI, buffers are torch tensors so that
 torch.distributed can move them) or any object with the same methods (the CPU tests plug in the oracle).
+
+On the GPU the whole transform is one library call, plk_ntt_sharded_dev (include/plonk_hip.h): the steps above and the exchange
+(grouped ncclSend / ncclRecv on the library's communicator) are enqueued on the library's stream, so a C++ or Rust host runs it
+without Python.  This module keeps the index maps, the step-by-step form for the CPU tests (oracle as the local transform, gloo as
+the transport) and the ranks-on-one-GPU rehearsals, which move the blocks themselves around the library's two halves.
 """
 from __future__ import annotations
 
@@ -66,27 +71,39 @@ class ShardedNtt:
         self.inv_base = mont(g_inv * pow(h, -g, R_MOD) % R_MOD)
         self.inv_ratio = mont(pow(w_n, -g, R_MOD))
         self.trivial_twiddle = coset is None and g == 0
+        self.coset_mont = None if coset is None else mont(h)
+        self.in_library = hasattr(ops, "sharded_half")          # the library computes the factors above itself
 
     # The two halves around the all-to-all are separate methods so that a test can walk several logical ranks through them
     # on one device and move the blocks itself.
     def forward_local(self, buf):
+        if self.in_library:
+            return self.ops.sharded_half(buf, self.log_n, False, self.coset_mont, 1, self.rank, self.world)
         self.ops.ntt(buf, self.log_m, False, self.local_coset)
         if self.world > 1 and not self.trivial_twiddle:
             self.ops.scale_powers(buf, self.m, self.fwd_base, self.fwd_ratio)
 
     def forward_finish(self, tmp):
+        if self.in_library:
+            return self.ops.sharded_half(tmp, self.log_n, False, self.coset_mont, 2, self.rank, self.world)
         self.ops.cross(tmp, self.log_g, self.m // self.world, False)
 
     def inverse_local(self, buf):
+        if self.in_library:
+            return self.ops.sharded_half(buf, self.log_n, True, self.coset_mont, 1, self.rank, self.world)
         self.ops.cross(buf, self.log_g, self.m // self.world, True)
 
     def inverse_finish(self, tmp):
+        if self.in_library:
+            return self.ops.sharded_half(tmp, self.log_n, True, self.coset_mont, 2, self.rank, self.world)
         if self.world > 1:
             self.ops.scale_powers(tmp, self.m, self.inv_base, self.inv_ratio)
         self.ops.ntt(tmp, self.log_m, True, self.local_coset)
 
     def forward(self, buf, tmp):
         """buf: this rank's M coefficients (cyclic layout), destroyed.  Returns the buffer that holds the evaluations."""
+        if getattr(self.ops, "library_exchange", False):
+            return tmp if self.ops.sharded_whole(buf, tmp, self.log_n, False, self.coset_mont) else buf
         self.forward_local(buf)
         if self.world == 1:
             return buf
@@ -96,6 +113,8 @@ class ShardedNtt:
 
     def inverse(self, buf, tmp):
         """buf: this rank's M evaluations (column-block layout), destroyed.  Returns the buffer that holds the coefficients."""
+        if getattr(self.ops, "library_exchange", False):
+            return tmp if self.ops.sharded_whole(buf, tmp, self.log_n, True, self.coset_mont) else buf
         if self.world == 1:
             self.inverse_finish(buf)
             return buf
@@ -115,13 +134,23 @@ def exchange_blocks(bufs):
 class HipOps:
     """Local steps on the GPU through the C ABI; buffers are torch int64 tensors of shape (count, 4) on the context's device.
 
-    exchange: all_to_all_single over the default process group.  With backend "nccl" (RCCL) the tensors travel device to
-    device over xGMI; with "gloo" (several ranks rehearsing on one GPU) they go through host memory."""
+    library_exchange = True (the context has a communicator, plk_comm_init): a transform is ONE call of plk_ntt_sharded_dev, the
+    exchange runs as grouped ncclSend / ncclRecv on the library's stream.  Otherwise the halves come from the library and the
+    blocks move through `exchange`: all_to_all_single over the default process group, device to device with backend "nccl", through
+    host memory with "gloo" (several ranks rehearsing on one GPU)."""
 
-    def __init__(self, ctx, device_index: int, backend: str = "nccl"):
+    def __init__(self, ctx, device_index: int, backend: str = "nccl", library_exchange: bool = False, self_exchange: bool = False):
         import torch
         self.torch, self.ctx, self.backend = torch, ctx, backend
         self.device = torch.device("cuda", device_index)
+        self.library_exchange = library_exchange
+        self.phase = 3 if self_exchange else 0               # 3: a single rank still sends to itself (exercises the communicator on one GPU)
+
+    def sharded_half(self, buf, log_n, inverse, coset, half, rank, world):
+        self.ctx.ntt_sharded_dev(buf.data_ptr(), 0, log_n, inverse=inverse, coset=coset, phase=half, rank=rank, world=world)
+
+    def sharded_whole(self, buf, tmp, log_n, inverse, coset) -> bool:
+        return self.ctx.ntt_sharded_dev(buf.data_ptr(), tmp.data_ptr(), log_n, inverse=inverse, coset=coset, phase=self.phase)
 
     def alloc(self, count: int):
         return self.torch.empty((count, 4), dtype=self.torch.int64, device=self.device)

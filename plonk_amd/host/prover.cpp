@@ -333,11 +333,17 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
         const uint64_t lens[9] = {in.len[0], in.len[1], in.len[2], in.len[3], in.len[4], in.len[5], in.len[6], n, t_len};
         int order[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
         msm_order(order, 9, lens);
-        int32_t ticket[9];
+        int32_t ticket[9], in_order[9];
+        const void* p9[9];
+        uint64_t l9[9], b9[9][12];
         for (int k = 0; k < 9; ++k) {
             const int i = order[k];
-            check(ctx, plk_kzg_open_begin(ctx, polys[i], lens[i], &blind[i][0].v[0], zeta.v, pk.opening_challenge.v, &ticket[i]));
+            p9[k] = polys[i]; l9[k] = lens[i];
+            memcpy(b9[k], &blind[i][0].v[0], 96);
         }
+        // one call for the round: the nine divisions by (X - zeta) run as one batch of launches, the sorts and accumulations follow in `order`
+        check(ctx, plk_kzg_open_begin_batch(ctx, 9, p9, l9, &b9[0][0], zeta.v, pk.opening_challenge.v, in_order));
+        for (int k = 0; k < 9; ++k) ticket[order[k]] = in_order[k];
         check(ctx, plk_kzg_submit(ctx));
         G1Affine w9[9];
         Fr rv9[9];

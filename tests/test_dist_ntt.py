@@ -165,3 +165,29 @@ def test_logical_ranks_on_the_gpu(ctx, orc, world, log_n, coset):
 @pytest.mark.gpu
 def test_two_processes_on_one_gpu_over_gloo(orc, tmp_path):
     _run_two_ranks(tmp_path, "gpu", 29642)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,coset", [(12, 5), (16, None), (20, 5)])
+def test_library_transform_on_a_one_rank_communicator(orc, log_n, coset):
+    """plk_ntt_sharded_dev as one call (local transform, twiddles, grouped ncclSend / ncclRecv on the library's communicator,
+    cross-rank butterflies, all on the library's stream) with the one rank a one-GPU box offers: the rank sends its block to
+    itself, so the RCCL point-to-point path runs; forward equals the oracle's transform, inverse returns the input bit for bit.
+    Without a communicator the call is refused."""
+    from plonk_amd.hip import Context, PlonkHipError
+    c = Context(0)
+    x, want = _inputs(orc, log_n, 300 + log_n, coset)
+    ops = dist_ntt.HipOps(c, 0, backend="nccl", library_exchange=True, self_exchange=True)
+    buf, tmp = ops.alloc(len(x)), ops.alloc(len(x))
+    ops.load(buf, x)
+    sn = dist_ntt.ShardedNtt(ops, 0, 1, log_n, coset)
+    with pytest.raises(PlonkHipError):
+        sn.forward(buf, tmp)
+    c.comm_init(c.comm_unique_id(), 0, 1)
+    ev = sn.forward(buf, tmp)
+    assert ev is tmp                                   # an exchange took place
+    assert np.array_equal(ops.read(ev), want)
+    back = sn.inverse(ev, buf)
+    assert back is buf and np.array_equal(ops.read(back), x)
+    del buf, tmp
+    c.close()

@@ -1,4 +1,6 @@
 """HIP library vs the CPU oracle, through the C ABI, on seeded inputs (bit-exact: all integer work)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -309,6 +311,95 @@ def test_kzg_commit_open(ctx, orc, srs, length):
     assert np.array_equal(rv, orv)
     want_ev = orc.poly_eval(coeffs, zeta) if length else np.zeros(4, dtype=np.uint64)
     assert np.array_equal(ev, want_ev)
+
+
+def test_open_batch_matches_single_openings_and_the_oracle(orc):
+    """plk_kzg_open_begin_batch (the nine openings of src/prover.rs:295-303 as one call): same points, random_v and evaluations as
+    plk_kzg_open on each polynomial and as the oracle's long division + MSM, for ragged lengths that include the empty polynomial,
+    constants, both sides of the division's block boundaries and, in one batch, polynomials on both sides of the change of block
+    size at 2^21 coefficients; ended in an order different from the one they were begun in; twice in a row on one context."""
+    from plonk_amd.hip import Context, PlonkHipError
+    c = Context(0)
+    n = (1 << 21) + 4096
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    c.srs_generate(tau, gs, n + 1)
+    one = orc.fr_from_ints([1])[0]
+    small = 1 << 14
+    g = orc.srs_powers(tau, one, 0, small + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+    assert np.array_equal(c.srs_read(0, 0, small + 1), g) and np.array_equal(c.srs_read(1, 0, 3), gg)
+    zeta, chal = rand_fr(orc, 2, 1234)
+    chal = orc.fr_from_ints([orc.fr_to_ints(chal)[0] & ((1 << 128) - 1)])[0]
+    lengths = [0, 1, 2, 3, 2047, 2048, 2049, 4097, 10000, small]
+    polys = [rand_fr(orc, k, 2000 + k) for k in lengths]
+    blinds = np.stack([rand_fr(orc, 3, 3000 + k) for k in lengths])
+    devs = [c.upload(p) for p in polys]
+    for rep in range(2):
+        tickets = c.open_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12), zeta, chal)
+        c.submit()
+        with pytest.raises(PlonkHipError):      # a second batch while tickets of the first are open is refused
+            c.open_begin_batch(devs[:1], lengths[:1], blinds[:1].reshape(1, 12), zeta, chal)
+        for i in (9, 0, 4, 1, 2, 3, 8, 7, 6, 5):
+            w, winf, rv, ev = c.open_end(tickets[i])
+            ow, oinf, orv = orc.kzg_open(g, gg, polys[i], blinds[i], zeta, chal)
+            assert winf == oinf and np.array_equal(w, ow), lengths[i]
+            want_ev = orc.poly_eval(polys[i], zeta) if lengths[i] else np.zeros(4, dtype=np.uint64)
+            assert np.array_equal(rv, orv) and np.array_equal(ev, want_ev), lengths[i]
+    for d in devs:
+        c.free(d)
+    # short and long block sizes in one batch, against the single-polynomial entry point (itself checked against the oracle at these
+    # lengths by test_division_around_the_change_of_block_size) and, for the evaluations, against the oracle's Horner rule
+    lengths = [(1 << 21) - 1, 1 << 21, (1 << 21) + 4095, 70001, 5]
+    def residues(count, seed):                 # any value below 2^252 is a residue in Montgomery form
+        a = np.random.default_rng(seed).integers(0, 1 << 63, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    polys = [residues(k, 4000 + i) for i, k in enumerate(lengths)]
+    blinds = np.stack([rand_fr(orc, 3, 5000 + i) for i in range(len(lengths))])
+    devs = [c.upload(p) for p in polys]
+    tickets = c.open_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12), zeta, chal)
+    batch = [c.open_end(t) for t in tickets]
+    for i, d in enumerate(devs):
+        single = c.open_end(c.open_begin(d, lengths[i], blinds[i], zeta, chal))
+        assert batch[i][1] == single[1] and all(np.array_equal(x, y) for x, y in zip((batch[i][0], batch[i][2], batch[i][3]), (single[0], single[2], single[3]))), lengths[i]
+        assert np.array_equal(batch[i][3], orc.poly_eval(polys[i], zeta)), lengths[i]
+        c.free(d)
+    c.close()
+
+
+def test_polynomial_overwritten_after_begin(ctx, orc, srs):
+    """The front work of every second ticket runs on a second stream.  A compute call that overwrites the polynomial after the
+    *_begin call that reads it (a transform in place, a copy, an upload) is ordered behind that read: the commitments and openings
+    below must be those of the original polynomials, whichever stream read them."""
+    srs_len = len(srs["g"])
+    k = min(4096, srs_len - 1)
+    polys = [rand_fr(orc, k, 800 + i) for i in range(6)]
+    blinds = [rand_fr(orc, 3, 820 + i) for i in range(6)]
+    zeta, chal = rand_fr(orc, 2, 77)
+    chal = orc.fr_from_ints([orc.fr_to_ints(chal)[0] & ((1 << 128) - 1)])[0]
+    junk = rand_fr(orc, k, 899)
+    d_junk = ctx.upload(junk)
+    devs = [ctx.upload(p) for p in polys]
+    tickets = []
+    for i, (d, b) in enumerate(zip(devs, blinds)):
+        tickets.append(ctx.commit_begin(d, k, b) if i % 3 != 2 else ctx.open_begin(d, k, b, zeta, chal))
+        # overwrite at once, three ways in turn
+        if i % 3 == 0:
+            ctx._ck(ctx.lib.plk_copy_dev(ctx.h, C.c_void_p(d), C.c_void_p(d_junk), C.c_uint64(k * 32), C.c_uint64(k * 32)))
+        elif i % 3 == 1:
+            ctx.upload_into(d, junk)
+        else:
+            ctx._ck(ctx.lib.plk_copy_dev(ctx.h, C.c_void_p(d), C.c_void_p(d_junk), C.c_uint64(0), C.c_uint64(k * 32)))   # zero fill
+    for i, (t, p, b) in enumerate(zip(tickets, polys, blinds)):
+        if i % 3 != 2:
+            got, inf = ctx.commit_end(t)
+            want = orc.kzg_commit(srs["g"], srs["gg"], p, b)
+            assert inf == want[1] and np.array_equal(got, want[0]), i
+        else:
+            w, winf, rv, ev = ctx.open_end(t)
+            ow, oinf, orv = orc.kzg_open(srs["g"], srs["gg"], p, b, zeta, chal)
+            assert winf == oinf and np.array_equal(w, ow) and np.array_equal(ev, orc.poly_eval(p, zeta)), i
+    for d in devs + [d_junk]:
+        ctx.free(d)
 
 
 def test_kzg_open_lengths_around_the_division_blocks(orc):

@@ -197,8 +197,13 @@ def test_proof_with_public_inputs(pk, orc):
     inputs = pk.prepare(tables)
     res = pk.prove(inputs, blinds, public_inputs=pub)
     plain = pk.prove(inputs, blinds)
-    g = pk.ctx.srs_read(0, 0, 4 * tables["n"] + 1); gg = pk.ctx.srs_read(1, 0, 3)
-    rc, want, ch, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], tables["log_n"], blinds, chal, public_inputs=pub)
+    # the checker's inputs are built on the CPU alone and compared with the device's before they are used
+    polys = independent_polys(orc, tables)
+    assert_polys_equal(inputs.polys, polys)
+    n4 = 4 * tables["n"]
+    g = orc.srs_powers(tau, orc.fr_from_ints([1])[0], 0, n4 + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+    assert np.array_equal(pk.ctx.srs_read(0, 0, n4 + 1), g) and np.array_equal(pk.ctx.srs_read(1, 0, 3), gg)
+    rc, want, ch, _ = orc.prove(g, gg, polys, tables["witness_flat"], tables["sigma"], tables["log_n"], blinds, chal, public_inputs=pub)
     inputs.close()
     assert rc == 0 and res.proof_bytes == want and np.array_equal(res.challenges, ch)
     assert plain.proof_bytes != res.proof_bytes
@@ -286,10 +291,20 @@ def test_proof_from_host_arrays_equals_the_resident_one(pk, orc, log_n):
     blinds = synth.seeded_scalars(27, 9)
     inputs = pk.prepare(tables)
     want = pk.prove(inputs, blinds)
-    polys = [np.ascontiguousarray(p) for p in inputs.polys]
+    # host arrays made by the CPU oracle alone (not read back from the device), and the oracle's own proof of them
+    own = independent_polys(orc, tables)
+    assert_polys_equal(inputs.polys, own)
+    polys = [np.ascontiguousarray(p) for p in own]
     wflat = np.ascontiguousarray(tables["witness_flat"], dtype=np.uint64); sigma = np.ascontiguousarray(tables["sigma"], dtype=np.uint64)
     got = pk.prove_host(polys, wflat, sigma, tables["log_n"], blinds)
     assert got.proof_bytes == want.proof_bytes and np.array_equal(got.challenges, want.challenges)
+    if log_n <= 14:   # the oracle's MSMs take minutes beyond that; 2^19 gates stay pinned through the resident proof (trapdoor tests cover that size)
+        n4 = 4 * tables["n"]
+        g = orc.srs_powers(tau, orc.fr_from_ints([1])[0], 0, n4 + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+        assert np.array_equal(pk.ctx.srs_read(0, 0, n4 + 1), g) and np.array_equal(pk.ctx.srs_read(1, 0, 3), gg)
+        rc, oracle_bytes, ch, _ = orc.prove(g, gg, own, tables["witness_flat"], tables["sigma"], tables["log_n"], blinds,
+                                            synth.to_mont([0x1234567890ABCDEF1122334455667788])[0])
+        assert rc == 0 and got.proof_bytes == oracle_bytes and np.array_equal(got.challenges, ch)
     # trailing zeros are stripped as DensePolynomial::from_coefficients_vec does
     padded = [np.concatenate([p, np.zeros((3, 4), np.uint64)]) for p in polys]
     assert pk.prove_host(padded, wflat, sigma, tables["log_n"], blinds).proof_bytes == want.proof_bytes

@@ -480,8 +480,13 @@ def test_sharded_proof_several_processes(orc, tmp_path, layout, world, log_gates
     pk.set_opening_challenge(chal)
     inputs = pk.prepare(tables)
     single = pk.prove(inputs, synth.seeded_scalars(27, 8)).proof_bytes
-    g = pk.ctx.srs_read(0, 0, 4 * tables["n"] + 1); gg = pk.ctx.srs_read(1, 0, 3)
-    rc, want, _, _ = orc.prove(g, gg, inputs.polys, tables["witness_flat"], tables["sigma"], log_gates, synth.seeded_scalars(27, 8), chal)
+    # the oracle proves from inputs made on the CPU alone (its own SRS powers and interpolations), compared with the device's first
+    polys = independent_polys(orc, tables)
+    assert_polys_equal(inputs.polys, polys)
+    n4 = 4 * tables["n"]
+    g = orc.srs_powers(tau, synth.to_mont([1])[0], 0, n4 + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+    assert np.array_equal(pk.ctx.srs_read(0, 0, n4 + 1), g) and np.array_equal(pk.ctx.srs_read(1, 0, 3), gg)
+    rc, want, _, _ = orc.prove(g, gg, polys, tables["witness_flat"], tables["sigma"], log_gates, synth.seeded_scalars(27, 8), chal)
     assert rc == 0 and single == want == proofs[0]
     inputs.close(); pk.close()
 

@@ -25,6 +25,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
     pmc ntt24 $c python3 tools/bench_msm.py --log-n 24 --reps 2 --ntt
     pmc quotient22 $c python3 tools/bench_msm.py --log-n 22 --reps 2 --quotient
 done
+# instruction-stream counters of the standalone 2^20-point MSM, and the figures bench.py quotes from these passes, tied to this build
+tools/sq_pass.sh $tag
+cp gpurun_out/sq_$tag.txt $out/msm20_pmc_sq.txt
+python3 tools/profile_current.py $out/bench20_pmc_FETCH_SIZE.txt $out/bench20_pmc_WRITE_SIZE.txt $out/msm20_pmc_sq.txt $out/bench20.json plonk_amd/lib/libplonk_hip.so $tag > $out/current.json
 find $out -name "*.db" -delete
 find $out -name "*kernel_trace.csv" -size +20M -delete
 echo done
