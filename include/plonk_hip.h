@@ -231,6 +231,9 @@ int32_t plk_kzg_open_end(plk_ctx* ctx, int32_t ticket, uint64_t w_xy[8], int32_t
  * ended before the next batch begins. */
 int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const void* const* coeffs_dev, const uint64_t* len, const uint64_t* blind,
                                  const uint64_t zeta[4], const uint64_t challenge[4], int32_t* tickets);
+/* plk_kzg_commit_begin for the `count` commitments of a round (src/prover.rs:150-156), same conventions as the batch of openings. */
+int32_t plk_kzg_commit_begin_batch(plk_ctx* ctx, uint32_t count, const void* const* coeffs_dev, const uint64_t* len, const uint64_t* blind,
+                                   int32_t* tickets);
 /* Ordering of a *_begin call against later calls on the same context: the polynomial a *_begin call reads (coeffs_dev) may be
  * overwritten by any later compute call of this context (plk_ntt_dev_enqueue in place, plk_copy_dev, plk_upload, a quotient or
  * grand product writing into it, ...): the library orders that call behind the ticket's last read.  Two exceptions, both by

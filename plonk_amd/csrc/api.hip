@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace plk {
@@ -321,7 +322,7 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     delete static_cast<StagePool*>(ctx->stage);
     ctx->stage = nullptr;
     ntt_release(ctx);
-    hipFree(ctx->tables); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
+    hipFree(ctx->tables); hipFree(ctx->tables_short); hipFree(ctx->marg_all_dev); hipHostFree(ctx->marg_all_host); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
     streams_release(ctx);
     delete ctx;
     return PLK_OK;
@@ -640,19 +641,113 @@ extern "C" int32_t plk_ntt_sharded_dev(plk_ctx* ctx, void* data_dev, void* tmp_d
 
 // ---- KZG commit ------------------------------------------------------------------------------------
 static void slot_release(plk_ctx* ctx, MsmSlot& s);
+// Lanes for the members of a round that is begun with one call (0 = first front stream, 1 = second), in the order given: the
+// alternation of single begins.  PLK_LANES_COMMIT / PLK_LANES_OPEN (a string of 0 and 1, one per member) override it for experiments.
+// Measured at 2^20 gates on one box against the alternation (30.6-30.8 ms): the 4n-coefficient s_sigma alone on the second stream
+// and everybody else on the first 31.3-31.5 ms; the same with the last members alternating again 31.4-31.5 ms; leader and s_sigma
+// on the second stream 31.0 ms.  Front work that gets ahead of the accumulation kernels only adds sorting kernels beside them.
+static void plan_lanes(plk_ctx* ctx, uint32_t count, const char* env_name, uint8_t* lane) {
+    for (uint32_t k = 0; k < count; ++k) lane[k] = 0;
+    if (ctx->detached || ctx->uploads_pending) return;
+    const char* ov = getenv(env_name);
+    if (ov && strlen(ov) >= count) { for (uint32_t k = 0; k < count; ++k) lane[k] = ov[k] == '1' ? 1 : 0; return; }
+    for (uint32_t k = 0; k < count; ++k) lane[k] = (ctx->lane_turn++ & 1) ? 1 : 0;
+}
+// Staging of a batch's small per-member data, so that it crosses PCIe in one transfer per direction: [member][16] hiding scalars of
+// openings, [member][8] remainders of their divisions, [member][24] blinding scalars of commitments.
+constexpr size_t BATCH_HW = 0, BATCH_RES = (size_t)MSM_SLOTS * 16, BATCH_BLIND = (size_t)MSM_SLOTS * 24, BATCH_WORDS = (size_t)MSM_SLOTS * 48;
+static int32_t batch_buffers(plk_ctx* ctx) {
+    if (ctx->batch_dev) return PLK_OK;
+    PLK_HIP(hipMalloc(&ctx->batch_dev, BATCH_WORDS * 4));
+    PLK_HIP(hipHostMalloc(&ctx->batch_host, BATCH_WORDS * 4, hipHostMallocDefault));
+    return PLK_OK;
+}
+static int32_t commit_begin_on(plk_ctx* ctx, int si, hipStream_t lane, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int idle_hint) {
+    MsmSlot& s = ctx->slot[si];
+    PLK_TRY(sort_after_compute(ctx, lane));
+    memcpy(s.blind_host, blind, 96);
+    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 96, hipMemcpyHostToDevice, lane));
+    PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)coeffs_dev, len, 0, 3, lane, idle_hint));
+    s.busy = true; s.kind = 1; s.in_batch = false;
+    return PLK_OK;
+}
 extern "C" int32_t plk_kzg_commit_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int32_t* ticket) {
     if (!ctx || !blind || !ticket || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     int si;
     PLK_TRY(msm_acquire_slot(ctx, &si));
-    MsmSlot& s = ctx->slot[si];
-    hipStream_t lane = front_lane(ctx);
-    PLK_TRY(sort_after_compute(ctx, lane));
-    memcpy(s.blind_host, blind, 96);
-    PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 96, hipMemcpyHostToDevice, lane));
-    PLK_TRY(msm_enqueue(ctx, s, (const uint32_t*)coeffs_dev, len, 0, 3, lane));
-    s.busy = true; s.kind = 1;
+    PLK_TRY(commit_begin_on(ctx, si, front_lane(ctx), coeffs_dev, len, blind, -1));
     *ticket = si;
+    return PLK_OK;
+}
+// The commitments of a round begun with one call (src/prover.rs:150-156: seven polynomials).  Same results as `count` calls of
+// plk_kzg_commit_begin in the same order; knowing the whole round, the library chooses the streams of the members' sorts itself.
+extern "C" int32_t plk_kzg_commit_begin_batch(plk_ctx* ctx, uint32_t count, const void* const* coeffs_dev, const uint64_t* len, const uint64_t* blind,
+                                              int32_t* tickets) {
+    if (!ctx || !count || !coeffs_dev || !len || !blind || !tickets) return PLK_ERR_INVALID_ARG;
+    if (count > (uint32_t)MSM_SLOTS) { ctx->err = "plk_kzg_commit_begin_batch: more polynomials than MSM slots"; return PLK_ERR_INVALID_ARG; }
+    for (uint32_t k = 0; k < count; ++k) if (len[k] && !coeffs_dev[k]) return PLK_ERR_INVALID_ARG;
+    if (ctx->batch_open) { ctx->err = "plk_kzg_commit_begin_batch: tickets of the previous batch are still open"; return PLK_ERR_INVALID_ARG; }
+    PLK_HIP(hipSetDevice(ctx->device));
+    uint32_t free_slots = 0;
+    for (const auto& s : ctx->slot) free_slots += s.busy ? 0 : 1;
+    if (free_slots < count) { ctx->err = "all MSM slots are busy: end an open ticket first"; return PLK_ERR_INVALID_ARG; }
+    // Members short enough for the narrow window plan share their launches: one sort and one accumulation for all of them, enqueued
+    // behind the others (whose launches are long enough to be worth having to themselves).  The blinding scalars of the group
+    // cross PCIe in one transfer.
+    PLK_TRY(batch_buffers(ctx));
+    uint32_t n_wide = 0;
+    for (uint32_t k = 0; k < count; ++k) n_wide += msm_plan_for(ctx, len[k], 0) == MSM_C ? 1 : 0;
+    uint8_t lanes[MSM_SLOTS];
+    plan_lanes(ctx, n_wide + (n_wide < count ? 1 : 0), "PLK_LANES_COMMIT", lanes);
+    bool idle = ctx->reduce_pending.empty();
+    for (const auto& s : ctx->slot) idle = idle && !s.busy;
+    MsmJob group[MSM_SLOTS];
+    uint32_t ng = 0, turn = 0;
+    int32_t rc = PLK_OK;
+    // slots first, in the order given; the group's members are collected before anything is enqueued, because the group is
+    // enqueued where its first member stands (a two-coefficient polynomial begun second has its result long before the round ends;
+    // enqueued last, its reduction would end the round behind everybody else's)
+    int si[MSM_SLOTS];
+    bool narrow[MSM_SLOTS];
+    for (uint32_t k = 0; k < count && rc == PLK_OK; ++k) {
+        rc = msm_acquire_slot(ctx, &si[k]);
+        if (rc != PLK_OK) break;
+        tickets[k] = si[k];
+        MsmSlot& s = ctx->slot[si[k]];
+        s.busy = true; s.kind = 1; s.in_batch = false;
+        narrow[k] = msm_plan_for(ctx, len[k], 0) != MSM_C;
+        if (!narrow[k]) continue;
+        s.in_batch = true;   // its blinding scalars sit in the batch's staging area until its sort has run
+        ++ctx->batch_open;
+        memcpy(ctx->batch_host + BATCH_BLIND + 24 * ng, blind + 12 * k, 96);
+        group[ng].slot = si[k]; group[ng].scalars = (const uint32_t*)coeffs_dev[k]; group[ng].k = len[k]; group[ng].base_offset = 0;
+        group[ng].n_blind = 3; group[ng].blind_dev = ctx->batch_dev + BATCH_BLIND + 24 * ng;
+        ++ng;
+    }
+    // Where the group goes: a group of a few terms (the two-coefficient s_id) where its first member stands, so that its result is
+    // there long before the round ends (enqueued last, its reduction would end the round behind everybody else's); a group with
+    // real work behind the members that have launches to themselves, which are the longer ones (measured at 2^16 gates: 4.02-4.05 ms
+    // per proof against 4.40 ms with the group in front).
+    uint64_t group_scalars = 0;
+    for (uint32_t g = 0; g < ng; ++g) group_scalars += group[g].k;
+    uint32_t group_pos = count;
+    if (group_scalars <= 4096) for (uint32_t k = count; k-- > 0;) if (narrow[k]) group_pos = k;
+    bool first = true;
+    for (uint32_t k = 0; k <= count && rc == PLK_OK; ++k) {
+        if (k == group_pos && ng) {
+            hipStream_t lane = lanes[turn] ? ctx->st_red : ctx->st_sort;
+            rc = sort_after_compute(ctx, lane);
+            if (rc == PLK_OK && hipMemcpyAsync(ctx->batch_dev + BATCH_BLIND, ctx->batch_host + BATCH_BLIND, (size_t)ng * 96, hipMemcpyHostToDevice, lane) != hipSuccess) rc = PLK_ERR_HIP;
+            if (rc == PLK_OK) rc = msm_enqueue_group(ctx, group, ng, lane, (idle && first) ? 1 : 0, MSM_C_SHORT);
+            ++turn; first = false;
+        }
+        if (k == count || narrow[k] || rc != PLK_OK) continue;
+        hipStream_t lane = lanes[turn] ? ctx->st_red : ctx->st_sort;
+        rc = commit_begin_on(ctx, si[k], lane, coeffs_dev[k], len[k], blind + 12 * k, (idle && first) ? 1 : 0);
+        ++turn; first = false;
+    }
+    if (rc != PLK_OK) { (void)plk_kzg_cancel(ctx); return rc; }   // the members begun so far are given up with everything else that is open
     return PLK_OK;
 }
 extern "C" int32_t plk_kzg_submit(plk_ctx* ctx) {
@@ -665,7 +760,7 @@ extern "C" int32_t plk_kzg_ready(plk_ctx* ctx, int32_t ticket, int32_t* ready) {
     if (!ctx || !ready || ticket < 0 || ticket >= MSM_SLOTS || !ctx->slot[ticket].busy) return PLK_ERR_INVALID_ARG;
     PLK_HIP(hipSetDevice(ctx->device));
     PLK_TRY(msm_flush_reductions(ctx));
-    const hipError_t e = hipEventQuery(ctx->slot[ticket].done);
+    const hipError_t e = hipEventQuery(ctx->slot[ctx->slot[ticket].done_owner].done);
     if (e != hipSuccess && e != hipErrorNotReady) { ctx->err = hipGetErrorString(e); return PLK_ERR_HIP; }
     *ready = e == hipSuccess ? 1 : 0;
     return PLK_OK;
@@ -725,6 +820,7 @@ extern "C" int32_t plk_kzg_commit(plk_ctx* ctx, const uint64_t* coeffs_host, uin
 
 // ---- KZG open --------------------------------------------------------------------------------------
 // hiding part of an opening, on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2 (-> hw, 16 words), random_v = r'(zeta)
+constexpr uint64_t BATCH_DIVISION_BELOW = (1ull << 19) + 1;   // rounds whose longest polynomial is shorter get their divisions as one batch
 static void hiding_part(const uint64_t* blind, const uint64_t zeta[4], const uint64_t challenge[4], uint64_t random_v[4], uint32_t* hw) {
     using namespace host;
     const el z = el_load(zeta), ch = el_load(challenge);
@@ -735,16 +831,11 @@ static void hiding_part(const uint64_t* blind, const uint64_t zeta[4], const uin
     memcpy(hw, hw0.v, 32);
     memcpy(hw + 8, hw1.v, 32);
 }
-extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
-                                      const uint64_t challenge[4], int32_t* ticket) {
-    if (!ctx || !blind || !zeta || !challenge || !ticket || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
-    PLK_HIP(hipSetDevice(ctx->device));
-    int si;
-    PLK_TRY(msm_acquire_slot(ctx, &si));
+static int32_t open_begin_on(plk_ctx* ctx, int si, hipStream_t lane, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                             const uint64_t challenge[4], int idle_hint) {
     MsmSlot& s = ctx->slot[si];
     PLK_TRY(grow(ctx, ctx->st_sort, &s.scal_dev, &s.scal_cap, (len + 1) * 8));
     PLK_TRY(grow(ctx, ctx->st_sort, &s.chain_dev, &s.chain_cap, division_work_words(len)));
-    hipStream_t lane = front_lane(ctx);
     PLK_TRY(sort_after_compute(ctx, lane));
     // witness polynomial of challenge*f: scalars challenge * h_i, i >= 1; h_0 = f(zeta)
     // a contiguous shard needs its own range of quotient coefficients only, a block-cyclic one has a part in every stretch
@@ -756,15 +847,27 @@ extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint
     s.eval_host = s.res_host; s.in_batch = false;
     hiding_part(blind, zeta, challenge, s.host_rv, s.blind_host);
     PLK_HIP(hipMemcpyAsync(s.blind_dev, s.blind_host, 64, hipMemcpyHostToDevice, lane));
-    PLK_TRY(msm_enqueue(ctx, s, s.scal_dev, len >= 2 ? len - 1 : 0, 0, 2, lane));
+    PLK_TRY(msm_enqueue(ctx, s, s.scal_dev, len >= 2 ? len - 1 : 0, 0, 2, lane, idle_hint));
     s.busy = true; s.kind = 2;
+    return PLK_OK;
+}
+extern "C" int32_t plk_kzg_open_begin(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
+                                      const uint64_t challenge[4], int32_t* ticket) {
+    if (!ctx || !blind || !zeta || !challenge || !ticket || (len && !coeffs_dev)) return PLK_ERR_INVALID_ARG;
+    PLK_HIP(hipSetDevice(ctx->device));
+    int si;
+    PLK_TRY(msm_acquire_slot(ctx, &si));
+    PLK_TRY(open_begin_on(ctx, si, front_lane(ctx), coeffs_dev, len, blind, zeta, challenge, -1));
     *ticket = si;
     return PLK_OK;
 }
-// All openings of a round at once (src/prover.rs:295-303: nine polynomials, one point, one challenge).  The divisions run as one
-// batch of launches at the head of the round, while the chip is idle, instead of three dependent launches per polynomial threaded
-// between the sorts and accumulations of the others; the sorts and accumulations then follow as for plk_kzg_open_begin, in the
-// order given.
+// All openings of a round at once (src/prover.rs:295-303: nine polynomials, one point, one challenge).  Short polynomials (all of
+// them of at most 2^19 coefficients): the divisions run as one batch of launches at the head of the round instead of three dependent
+// launches per polynomial threaded between the sorts and accumulations of the others (nine divisions of 2^16 coefficients are
+// latency and nothing else); the sorts and accumulations then follow as for plk_kzg_open_begin, in the order given.  Long
+// polynomials: each member's division stays in front of its own sort (batched, the divisions delay the round's first accumulation
+// kernel, and without divisions between them the sorts of the two front streams bunch up beside the accumulation kernels: measured
+// 0.3-0.7 ms slower at 2^20 gates).
 extern "C" int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const void* const* coeffs_dev, const uint64_t* len, const uint64_t* blind,
                                             const uint64_t zeta[4], const uint64_t challenge[4], int32_t* tickets) {
     if (!ctx || !count || !coeffs_dev || !len || !blind || !zeta || !challenge || !tickets) return PLK_ERR_INVALID_ARG;
@@ -772,19 +875,29 @@ extern "C" int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const 
     for (uint32_t k = 0; k < count; ++k) if (len[k] && !coeffs_dev[k]) return PLK_ERR_INVALID_ARG;
     if (ctx->batch_open) { ctx->err = "plk_kzg_open_begin_batch: tickets of the previous batch are still open"; return PLK_ERR_INVALID_ARG; }
     PLK_HIP(hipSetDevice(ctx->device));
-    if (!ctx->batch_dev) {
-        PLK_HIP(hipMalloc(&ctx->batch_dev, (size_t)MSM_SLOTS * 24 * 4));
-        PLK_HIP(hipHostMalloc(&ctx->batch_host, (size_t)MSM_SLOTS * 24 * 4, hipHostMallocDefault));
-    }
+    PLK_TRY(batch_buffers(ctx));
     uint32_t free_slots = 0;
     bool idle = ctx->reduce_pending.empty();
     for (const auto& s : ctx->slot) { free_slots += s.busy ? 0 : 1; idle = idle && !s.busy; }
     if (free_slots < count) { ctx->err = "all MSM slots are busy: end an open ticket first"; return PLK_ERR_INVALID_ARG; }
-    // layout of the batch buffers: [count][16] hiding scalars, then [count][8] remainders
-    uint32_t* hw_dev = ctx->batch_dev;
-    uint32_t* res_dev = ctx->batch_dev + (size_t)MSM_SLOTS * 16;
-    uint32_t* hw_host = ctx->batch_host;
-    uint32_t* res_host = ctx->batch_host + (size_t)MSM_SLOTS * 16;
+    uint64_t longest = 0;
+    for (uint32_t k = 0; k < count; ++k) longest = std::max(longest, len[k]);
+    if (longest >= BATCH_DIVISION_BELOW) {
+        uint8_t lanes[MSM_SLOTS];
+        plan_lanes(ctx, count, "PLK_LANES_OPEN", lanes);
+        for (uint32_t k = 0; k < count; ++k) {
+            int si;
+            int32_t rc = msm_acquire_slot(ctx, &si);
+            if (rc == PLK_OK) rc = open_begin_on(ctx, si, lanes[k] ? ctx->st_red : ctx->st_sort, coeffs_dev[k], len[k], blind + 12 * k, zeta, challenge, -1);
+            if (rc != PLK_OK) { (void)plk_kzg_cancel(ctx); return rc; }
+            tickets[k] = si;
+        }
+        return PLK_OK;
+    }
+    uint32_t* hw_dev = ctx->batch_dev + BATCH_HW;
+    uint32_t* res_dev = ctx->batch_dev + BATCH_RES;
+    uint32_t* hw_host = ctx->batch_host + BATCH_HW;
+    uint32_t* res_host = ctx->batch_host + BATCH_RES;
     const bool cyclic = ctx->cyc_world > 1;
     int si[MSM_SLOTS];
     DivJob jobs[MSM_SLOTS];
@@ -804,18 +917,47 @@ extern "C" int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const 
         hiding_part(blind + 12 * k, zeta, challenge, s.host_rv, hw_host + 16 * k);
         s.eval_host = res_host + 8 * k;
     }
-    // the divisions go to the front stream itself: the first sort follows them there, the second front stream waits for them below
-    hipStream_t st = ctx->st_sort;
-    if (rc == PLK_OK && !ctx->detached) rc = order_streams(ctx, ctx->stream, st);
-    if (rc == PLK_OK) rc = division_enqueue_batch(ctx, st, count, jobs, zeta, challenge);
-    if (rc == PLK_OK && hipMemcpyAsync(res_host, res_dev, (size_t)count * 32, hipMemcpyDeviceToHost, st) != hipSuccess) rc = PLK_ERR_HIP;
-    if (rc == PLK_OK && hipMemcpyAsync(hw_dev, hw_host, (size_t)count * 64, hipMemcpyHostToDevice, st) != hipSuccess) rc = PLK_ERR_HIP;
+    // All divisions as one batch on the first front stream (polynomials this short: latency and nothing else), then the sorts:
+    // members on the wide window plan one by one on alternating front streams, the members short enough for the narrow plan as
+    // one group that shares its launches.
+    hipStream_t st0 = ctx->st_sort;
+    if (rc == PLK_OK && !ctx->detached) rc = order_streams(ctx, ctx->stream, st0);
+    if (rc == PLK_OK && hipMemcpyAsync(hw_dev, hw_host, (size_t)count * 64, hipMemcpyHostToDevice, st0) != hipSuccess) rc = PLK_ERR_HIP;
+    if (rc == PLK_OK) rc = division_enqueue_batch(ctx, st0, count, jobs, zeta, challenge);
+    if (rc == PLK_OK && hipMemcpyAsync(res_host, res_dev, (size_t)count * 32, hipMemcpyDeviceToHost, st0) != hipSuccess) rc = PLK_ERR_HIP;
+    MsmJob group[MSM_SLOTS];
+    uint32_t ng = 0;
+    bool narrow[MSM_SLOTS];
     for (uint32_t k = 0; k < count && rc == PLK_OK; ++k) {
         MsmSlot& s = ctx->slot[si[k]];
-        hipStream_t lane = front_lane(ctx);
-        rc = sort_after_compute(ctx, lane);   // the second front stream waits for the divisions (and the sorts before this one)
-        if (rc == PLK_OK) rc = msm_enqueue(ctx, s, s.scal_dev, len[k] >= 2 ? len[k] - 1 : 0, 0, 2, lane, (idle && k == 0) ? 1 : 0, hw_dev + 16 * k);
+        const uint64_t scalars = len[k] >= 2 ? len[k] - 1 : 0;
         tickets[k] = si[k];
+        narrow[k] = msm_plan_for(ctx, scalars, 0) == MSM_C_SHORT;
+        if (!narrow[k]) continue;
+        group[ng].slot = si[k]; group[ng].scalars = s.scal_dev; group[ng].k = scalars; group[ng].base_offset = 0;
+        group[ng].n_blind = 2; group[ng].blind_dev = hw_dev + 16 * k;
+        ++ng;
+    }
+    // the group goes where its first member stands when it is a few terms only, behind the members with launches of their own otherwise
+    // (see plk_kzg_commit_begin_batch)
+    uint64_t group_scalars = 0;
+    for (uint32_t g = 0; g < ng; ++g) group_scalars += group[g].k;
+    uint32_t group_pos = count;
+    if (group_scalars <= 4096) for (uint32_t k = count; k-- > 0;) if (narrow[k]) group_pos = k;
+    bool first = true;
+    for (uint32_t k = 0; k <= count && rc == PLK_OK; ++k) {
+        if (k == group_pos && ng) {
+            hipStream_t lane = front_lane(ctx);
+            rc = sort_after_compute(ctx, lane);   // the second front stream waits for the divisions (and the sorts before this one)
+            if (rc == PLK_OK) rc = msm_enqueue_group(ctx, group, ng, lane, (idle && first) ? 1 : 0, MSM_C_SHORT);
+            first = false;
+        }
+        if (k == count || narrow[k] || rc != PLK_OK) continue;
+        MsmSlot& s = ctx->slot[si[k]];
+        hipStream_t lane = front_lane(ctx);
+        rc = sort_after_compute(ctx, lane);
+        if (rc == PLK_OK) rc = msm_enqueue(ctx, s, s.scal_dev, len[k] >= 2 ? len[k] - 1 : 0, 0, 2, lane, (idle && first) ? 1 : 0, hw_dev + 16 * k);
+        first = false;
     }
     if (rc != PLK_OK) {   // what was enqueued runs to completion on buffers that stay valid; the slots are handed back
         (void)hipStreamSynchronize(ctx->st_sort); (void)hipStreamSynchronize(ctx->st_red);

@@ -12,13 +12,25 @@
 
 namespace plk {
 
-// Window layout of the MSM: 16 signed 16-bit digits per scalar, one shared set of 2^15 buckets
-// (digit magnitude 1..32768 -> bucket 0..32767) because every window has its own table of 2^(16 j) * P.
-constexpr int MSM_C = 16;
-constexpr int MSM_WINDOWS = 16;
-constexpr int MSM_BUCKETS = 1 << 15;
+// Window layouts of the MSM.  Every window has its own table of 2^(C j) * P, so all windows of an MSM share one set of 2^(C-1)
+// buckets (digit magnitude 1..2^(C-1) -> bucket 0..2^(C-1)-1).  Two widths: 16-bit windows (16 signed digits per scalar, 2^15
+// buckets) for long MSMs, 13-bit windows (20 digits, 2^12 buckets) for short ones, where the reduction of the buckets, whose cost
+// does not depend on the MSM's length, would otherwise be a fifth of the work and most of the latency.
+constexpr int MSM_C = 16, MSM_C_SHORT = 13;
+template <int C>
+struct MsmPlan {
+    static constexpr int WINDOWS = (254 + C - 1) / C;                 // 16 | 20: the top window's digit is small, its carry never leaves the scalar
+    static constexpr int BUCKETS = 1 << (C - 1);                      // 32768 | 4096
+    static constexpr int DIGIT_WORDS = WINDOWS / 2;                   // two-byte digit codes per scalar, as 32-bit words
+    static constexpr int FIELDS = (C - 1 + 3) / 4;                    // bit-fields of the bucket index in the marginal sums: 4 | 3
+    static constexpr int LAST_BITS = C - 1 - 4 * (FIELDS - 1);        // width of the top field: 3 | 4 (the others have 4 bits)
+    static constexpr int MARGINALS = 16 * (FIELDS - 1) + (1 << LAST_BITS);   // 56 | 48 partial sums handed to the host
+    static_assert(WINDOWS % 2 == 0 && WINDOWS * C >= 255, "window layout");
+};
+constexpr int MSM_MAX_WINDOWS = 20;
+constexpr int MSM_BUCKETS = MsmPlan<MSM_C>::BUCKETS;   // the larger of the two bucket counts: sizes the per-slot scratch
 constexpr int MSM_SLOTS = 10;           // MSMs in flight (a round of the prover enqueues up to nine at once)
-constexpr int MSM_MARGINALS = 56;       // 16 + 16 + 16 + 8 partial sums handed to the host
+constexpr int MSM_MARGINALS = 56;       // the larger of the two plans' outputs
 constexpr int XYZZ_WORDS = 36;          // unnormalised point in device scratch: 4 coordinates x 9 limbs
 
 struct MsmSeg {
@@ -74,6 +86,9 @@ struct MsmSlot {
     int kind = 0;                      // 0 msm, 1 commit, 2 open
     uint64_t max_entries = 0;          // of the job in flight: its accumulation time is proportional to this
     int acc_stream = 0;                // which of the two accumulation streams runs it
+    int plan_c = MSM_C;                // window width of the job in flight
+    int ev_owner = 0;                  // slot whose `accumulated` event covers this job (members of a batch share their launches)
+    int done_owner = 0;                // slot whose `done` event covers this job's read-back
     uint32_t acc_blocks = 0;
     uint64_t host_rv[4], host_chal[4]; // opening: values finished on the host
     const uint32_t* eval_host = nullptr;   // opening: where the remainder f(zeta) arrives (res_host, or the batch's pinned buffer)
@@ -114,7 +129,12 @@ struct plk_ctx {
     uint32_t cyc_world = 1, cyc_rank = 0, cyc_log_block = 0;   // cyc_world > 1: block-cyclic shard (shard_first unused, shard_len = points held)
     bool has_gamma = false;
     uint64_t table_stride = 0;         // points per window table: shard_len + 3 (gamma powers at the end)
-    uint32_t* tables = nullptr;        // [MSM_WINDOWS][table_stride] affine, 16 words each, x*2^261 form
+    uint32_t* tables = nullptr;        // [16 windows][table_stride] affine, 16 words each, x*2^261 form: 2^(16 j) P
+    uint32_t* tables_short = nullptr;  // [20 windows][table_stride]: 2^(13 j) P, for the MSMs short enough for the narrow plan
+    uint64_t short_max = 0;            // MSMs of at most this many scalars take the narrow plan (0: never)
+    uint64_t short_len = 0, short_stride = 0;   // points the narrow tables cover (a prefix of this rank's points), points per narrow table (prefix + 3 gamma powers)
+    uint32_t* marg_all_dev = nullptr;  // [MSM_SLOTS][MSM_MARGINALS][32]: the slots' outputs side by side, so that a batch of reductions is read back with one copy
+    uint32_t* marg_all_host = nullptr; // pinned
     // NTT
     std::map<int, uint32_t*> twiddles; // log_n -> w^i for i < n/2, x*2^261 form
     std::map<std::vector<uint64_t>, uint32_t*> coset_factors;   // per-element factor tables of the large transforms (x*2^261 form): (log_n, inverse, generator) -> g^i or n^-1 g^-i; (~0, log_n, inverse, pass, ...) -> inter-pass twiddles

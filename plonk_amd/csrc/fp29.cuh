@@ -240,6 +240,80 @@ PLK_HD fe reduce(const fe& a) {
     return r;
 }
 
+// ---- product with a fixed operand (Shoup) ---------------------------------------------------------------------------------
+// For a factor w that is used many times (a twiddle), the quotient of x * w by p can be estimated from a precomputed
+// wq = floor(w * 2^261 / p):  q = floor(x * wq / 2^261)  is at most 2 below floor(x * w / p), so  r = x * w - q * p  lies in [0, 3p).
+// There is no chain of reduction multipliers (each Montgomery column waits for the multiplier of the column before) and no
+// multiply by -p^-1: 53 multiply-adds for the upper columns of x * wq (columns 0..6 only matter through their carry, which is
+// below 2^-23 of a unit of q), 45 for the low nine columns of x * w, 45 for those of q * (2^261 - p); r is their sum modulo 2^261.
+// The product is a plain one, x * w mod p, with no Montgomery factor: data in the x * 2^256 form keeps its form.
+//
+// Needs  x < 2^261 (bound 169)  and  limb(x) <= 2.5 * 2^30  (18 partial products of a column stay below 2^64);  w canonical, wq < 2^261,
+// both normalized.  Returns a normalized value with bound 3.
+struct shoup {
+    fe w, wq;
+};
+template <class F>
+PLK_HD fe mul_shoup(const fe& x, const shoup& c) {
+    uint64_t acc = 0;
+    uint32_t q[9];
+    // upper columns of x * wq: columns 7 and 8 feed the carry only
+#pragma unroll
+    for (int k = 7; k < 17; ++k) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); ++i) acc = mad_vv(x.v[i], c.wq.v[k - i], acc);
+        if (k >= 9) q[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    q[8] = (uint32_t)acc;
+    // low nine columns of x * w + q * (2^261 - p)
+    fe r;
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc = mad_vv(x.v[i], c.w.v[k - i], acc);
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc = mad_vs(q[i], F::NEGP[k - i], acc);
+        r.v[k] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    return r;   // r < 3p < 2^256: limb 8 is below 2^24, nothing is lost above it
+}
+// The pair (w, wq) from w * 2^261 mod p, canonical (the form the twiddle tables hold):  w * 2^261 = wq * p + s  with
+// s = w * 2^261 mod p, so  wq = -s * p^-1 mod 2^261  (the division is exact), the low half of one product.
+template <class F>
+PLK_HD shoup shoup_of(const fe& s) {
+    shoup c;
+    c.w = reduce<F>(mul<F>(s, fe_const(F::RAW1)));
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc = mad_vs(s.v[i], F::NPINV[k - i], acc);
+        c.wq.v[k] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    return c;
+}
+// (p - w, its quotient factor) from (w, wq), w != 0:  (p - w) 2^261 = (2^261 - 1 - wq) p + (p - s)
+template <class F>
+PLK_HD shoup shoup_neg(const shoup& c) {
+    shoup n;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t t = F::P[i] - c.w.v[i] - borrow;
+        borrow = t >> 31;
+        n.w.v[i] = t & M29;
+        n.wq.v[i] = M29 - c.wq.v[i];
+    }
+    return n;
+}
+// normalized value with bound 3  ->  canonical representative in [0, p)
+template <class F>
+PLK_HD fe reduce3(const fe& a) { return reduce<F>(reduce<F>(a)); }
+
 // exact test "a == 0 (mod p)" for a normalized value with bound 64.
 // a = k*p forces k = a[0] * p^-1 mod 2^29, so almost every non-multiple is rejected by one multiply.
 template <class F>

@@ -17,6 +17,16 @@ int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint6
 // (latency-bound, a fraction of the chip each) follow each other and feed the accumulation kernels too slowly.  One stream while
 // compute work is detached to the reduction stream or uploads are queued on it.
 hipStream_t front_lane(plk_ctx* ctx);
+// Several MSMs that share one window plan and their launches (one sort, one accumulation): the short MSMs of a round.
+struct MsmJob {
+    int slot;                    // index into ctx->slot
+    const uint32_t* scalars;     // device
+    uint64_t k, base_offset;
+    uint32_t n_blind;
+    const uint32_t* blind_dev;   // null: the slot's own buffer
+};
+int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset);   // MSM_C or MSM_C_SHORT
+int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStream_t lane, int idle_hint, int plan_c);
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);   // enqueues the pending reductions first
 int32_t msm_flush_reductions(plk_ctx* ctx);
 void slot_destroy(MsmSlot& s);

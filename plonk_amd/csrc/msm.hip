@@ -1,20 +1,21 @@
 // Pippenger MSM over BN254 G1 for gfx950, and the SRS tables it runs on.
 //
-// Layout.  The SRS is resident as MSM_WINDOWS tables T[j][i] = 2^(16 j) * P_i (affine, 64 B per point,
-// coordinates in the 2^261 Montgomery form of fp29.cuh).  With one table per window all windows share a
-// single set of 2^15 buckets:  sum_i s_i P_i = sum_k k * B_k,  B_k = sum of +-T[j][i] over all (i, j)
-// whose signed 16-bit digit has magnitude k.
+// Layout.  The SRS is resident as tables T[j][i] = 2^(C j) * P_i, one per window j (affine, 64 B per point, coordinates in the
+// 2^261 Montgomery form of fp29.cuh).  With one table per window all windows share a single set of 2^(C-1) buckets:
+// sum_i s_i P_i = sum_k k * B_k,  B_k = sum of +-T[j][i] over all (i, j) whose signed C-bit digit has magnitude k.
+// Two plans (MsmPlan in common.cuh): C = 16 over the whole SRS, C = 13 over a prefix of it for short MSMs.
 //
 // Pipeline of one MSM (sort on a front stream, accumulation and reduction on streams of their own, several MSMs in flight):
-//   digits + count : signed 16-bit digits of every scalar as 16 two-byte codes, histogram of 256 partitions per workgroup
+//   digits + count : signed digits of every scalar as two-byte codes, histogram of 256 partitions per workgroup
 //   partition      : every workgroup appends its 8-byte records to its own piece of each partition (upper 8 bucket bits)
-//   buckets        : one workgroup per partition spreads the records over the partition's 128 buckets -> entries sorted by bucket
+//   buckets        : one workgroup per partition spreads the records over the partition's buckets -> entries sorted by bucket
 //   accumulate: every lane adds one run of consecutive sorted entries (mixed XYZZ additions); sums of runs that end inside a
 //               bucket are joined by the fold kernel                              -> bucket_sums
-//   marginals : sum_k k B_k is linear in the bits of k; the bucket index is cut into 4 bit-fields and the
-//               56 sums "all buckets whose field d equals v" come from serial partial sums and one tree each
+//   marginals : sum_k k B_k is linear in the bits of k; the bucket index is cut into 4-bit fields and the sums "all buckets whose
+//               field d equals v" come from serial partial sums and one tree each
 //   host      : ~130 point additions and one inversion finish the job (a GPU lane needs ~6 us per point
 //               addition, a host core ~0.3 us, so the serial tail belongs on the host).
+// Every kernel takes a batch (blockIdx.y or a block table selects the member): the short MSMs of a round share their launches.
 #include "common.cuh"
 #include "host_math.hpp"
 #include "kernels.h"
@@ -24,17 +25,21 @@
 namespace plk {
 
 // ------------------------------------------------------------------------------------------ scalars -> digits
-// scalar in memory: x * 2^256, canonical.  Returns 16 signed digits d_j in [-2^15+1, 2^15] with x = sum d_j 2^(16 j).
+// scalar in memory: x * 2^256, canonical.  Returns WINDOWS signed digits d_j in [-2^(C-1)+1, 2^(C-1)] with x = sum d_j 2^(C j).
+template <int C>
 __device__ __forceinline__ void scalar_digits(const uint32_t* sw, int32_t* d) {   // sw: the scalar's eight words, already loaded
     const fe s = reduce<FrP>(mul<FrP>(unpack(sw), fe_const(FrP::RAW32)));
     uint32_t w[8];
     pack(s, w);
     uint32_t carry = 0;
 #pragma unroll
-    for (int j = 0; j < MSM_WINDOWS; ++j) {
-        uint32_t raw = ((w[j >> 1] >> (16 * (j & 1))) & 0xffffu) + carry;
-        carry = raw > 0x8000u ? 1u : 0u;
-        d[j] = (int32_t)raw - (int32_t)(carry << 16);
+    for (int j = 0; j < MsmPlan<C>::WINDOWS; ++j) {
+        const int bit = C * j, wi = bit >> 5, off = bit & 31;
+        uint32_t raw = w[wi] >> off;
+        if (off + C > 32 && wi + 1 < 8) raw |= w[wi + 1] << (32 - off);
+        raw = (raw & ((1u << C) - 1u)) + carry;
+        carry = raw > (1u << (C - 1)) ? 1u : 0u;
+        d[j] = (int32_t)raw - (int32_t)(carry << C);
     }
 }
 __device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint32_t idx, uint32_t* table_index) {
@@ -65,16 +70,41 @@ __device__ __forceinline__ uint32_t digit_code(int32_t d) {
 // A one-level scatter (every workgroup writes each entry straight to its bucket's slot, cursors per workgroup and bucket) hands
 // every (chunk, bucket) pair its own few slots, so each 4-byte store lands in a line that no other store of the same workgroup
 // completes soon: the line leaves the L2 with four valid bytes and memory sees one partial write per entry (measured: 7.5 times the
-// entry bytes written, 2.35 ms per proof of 2^20 gates lost by the accumulation kernels beside it).  Here the entries first go to SORT_PARTS = 256 partitions by the upper eight bits of their bucket (8-byte records:
-// entry word + lower seven bits), each workgroup appending to its own reserved piece of a partition, so the 256 lines it has open
-// fill within an iteration or two; then one workgroup per partition spreads its records over the partition's 128 buckets, all
-// inside a region of about 256 KB that stays in the L2 until its lines are full.  Three launches; 1 KB of LDS per workgroup.
-constexpr int SORT_PARTS = 256, SORT_PART_BUCKETS = MSM_BUCKETS / SORT_PARTS;   // 128 buckets per partition
+// entry bytes written, 2.35 ms per proof of 2^20 gates lost by the accumulation kernels beside it).  Here the entries first go to
+// SORT_PARTS = 256 partitions by the upper eight bits of their bucket (8-byte records: entry word + the lower bucket bits), each
+// workgroup appending to its own reserved piece of a partition, so the 256 lines it has open fill within an iteration or two; then
+// one workgroup per partition spreads its records over the partition's buckets (128 with 16-bit windows, 16 with 13-bit ones), all
+// inside a region that stays in the L2 until its lines are full.  Three launches; 1 KB of LDS per workgroup.
+constexpr int SORT_PARTS = 256;
 constexpr int SORT_MAX_BLOCKS = 512;                                            // workgroups of the first two kernels (rows of the count matrix)
-static_assert(SORT_PART_BUCKETS == 128, "records keep seven bucket bits");
-// digits of every scalar (sixteen two-byte codes, 32 bytes per scalar) + this workgroup's histogram of partitions -> part_counts[workgroup][SORT_PARTS]
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(MsmSegs segs, uint32_t chunk, uint32_t* __restrict__ digits, uint32_t* __restrict__ part_counts) {
+template <int C>
+struct SortPlan {
+    static constexpr int PART_BITS = C - 1 - 8;                                 // bucket bits below the partition: 7 | 4
+    static constexpr int PART_BUCKETS = 1 << PART_BITS;                         // buckets per partition: 128 | 16
+};
+// What the three kernels need to know about every member of a batch.
+struct SortBatch {
+    MsmSegs segs[MSM_SLOTS];
+    uint32_t chunk[MSM_SLOTS];         // scalars per workgroup of the first two kernels
+    uint32_t nblocks[MSM_SLOTS];       // workgroups of the member (the launch has the largest count; the others leave)
+    uint32_t* digits[MSM_SLOTS];       // digit codes, DIGIT_WORDS words per scalar
+    uint32_t* counts[MSM_SLOTS];       // [workgroup][SORT_PARTS]
+    uint32_t* part_start[MSM_SLOTS];   // SORT_PARTS + 1 words
+    uint64_t* records[MSM_SLOTS];
+    uint32_t* bucket_start[MSM_SLOTS]; // BUCKETS + 1 words
+    uint32_t* entries[MSM_SLOTS];
+    uint32_t table_stride;
+};
+// digits of every scalar (WINDOWS two-byte codes) + this workgroup's histogram of partitions -> counts[workgroup][SORT_PARTS]
+template <int C>
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(SortBatch sb) {
     PLK_SIDE_PRIO();
+    constexpr int W = MsmPlan<C>::WINDOWS, DW = MsmPlan<C>::DIGIT_WORDS;
+    const uint32_t mb = blockIdx.y;
+    if (blockIdx.x >= sb.nblocks[mb]) return;
+    const MsmSegs& segs = sb.segs[mb];
+    uint32_t* __restrict__ digits = sb.digits[mb];
+    const uint32_t chunk = sb.chunk[mb];
     __shared__ uint32_t hist[SORT_PARTS];
     hist[threadIdx.x] = 0;
     __syncthreads();
@@ -86,29 +116,40 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(MsmSegs segs
 #pragma unroll
         for (int i = 0; i < 8; ++i) sw[i] = sw_next[i];
         if (idx + SORT_THREADS < hi) load8(seg_scalar(segs, idx + SORT_THREADS, &ti), sw_next);   // in flight while this scalar is converted
-        int32_t d[MSM_WINDOWS];
-        scalar_digits(sw, d);
-        uint32_t w[MSM_WINDOWS / 2];
+        int32_t d[W];
+        scalar_digits<C>(sw, d);
+        uint32_t w[DW];
 #pragma unroll
-        for (int j = 0; j < MSM_WINDOWS; j += 2) {
+        for (int j = 0; j < W; j += 2) {
             const uint32_t c0 = digit_code(d[j]), c1 = digit_code(d[j + 1]);
             w[j / 2] = c0 | (c1 << 16);
-            if (c0 != DIGIT_NONE) atomicAdd(&hist[(c0 & 0x7fffu) >> 7], 1u);
-            if (c1 != DIGIT_NONE) atomicAdd(&hist[(c1 & 0x7fffu) >> 7], 1u);
+            if (c0 != DIGIT_NONE) atomicAdd(&hist[(c0 & 0x7fffu) >> SortPlan<C>::PART_BITS], 1u);
+            if (c1 != DIGIT_NONE) atomicAdd(&hist[(c1 & 0x7fffu) >> SortPlan<C>::PART_BITS], 1u);
         }
-        store8(digits + 8ull * idx, w);
+        uint2* dst = reinterpret_cast<uint2*>(digits + (size_t)DW * idx);      // DW is even: eight-byte stores
+#pragma unroll
+        for (int i = 0; i < DW / 2; ++i) dst[i] = make_uint2(w[2 * i], w[2 * i + 1]);
     }
     __syncthreads();
-    part_counts[(size_t)blockIdx.x * SORT_PARTS + threadIdx.x] = hist[threadIdx.x];
+    sb.counts[mb][(size_t)blockIdx.x * SORT_PARTS + threadIdx.x] = hist[threadIdx.x];
 }
-// records[slot] = entry word | (lower seven bucket bits << 32), appended to this workgroup's piece of the record's partition
+// records[slot] = entry word | (lower bucket bits << 32), appended to this workgroup's piece of the record's partition
 // Every workgroup works out where its pieces begin from the whole count matrix (nblocks x 256 words, read from the L2): thread p sums
 // partition p over all workgroups (the partition's size) and over the workgroups before its own, a scan over p gives the
 // partition's start.  A kernel of its own for this took one more launch and, as a single workgroup beside the accumulation waves,
 // as long as the partitioning itself.  Workgroup 0 also publishes the partition starts for k_sort_buckets.
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(MsmSegs segs, uint32_t chunk, const uint32_t* __restrict__ digits, const uint32_t* __restrict__ part_counts,
-                                                                 uint32_t nblocks, uint32_t* __restrict__ part_start, uint32_t table_stride, uint64_t* __restrict__ records) {
+template <int C>
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(SortBatch sb) {
     PLK_SIDE_PRIO();
+    constexpr int W = MsmPlan<C>::WINDOWS, DW = MsmPlan<C>::DIGIT_WORDS;
+    const uint32_t mb = blockIdx.y, nblocks = sb.nblocks[mb];
+    if (blockIdx.x >= nblocks) return;
+    const MsmSegs& segs = sb.segs[mb];
+    const uint32_t* __restrict__ digits = sb.digits[mb];
+    const uint32_t* __restrict__ part_counts = sb.counts[mb];
+    uint32_t* __restrict__ part_start = sb.part_start[mb];
+    uint64_t* __restrict__ records = sb.records[mb];
+    const uint32_t chunk = sb.chunk[mb], table_stride = sb.table_stride;
     __shared__ uint32_t cursor[SORT_PARTS];
     __shared__ uint32_t wave_sum[SORT_THREADS / 64];
     {
@@ -133,7 +174,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(MsmSegs segs, u
         if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
         uint32_t start = incl - total;
-        for (uint32_t k = 0; k < wave; ++k) start += wave_sum[k];
+        for (uint32_t k2 = 0; k2 < wave; ++k2) start += wave_sum[k2];
         cursor[p] = start + before;
         if (blockIdx.x == 0) {
             part_start[p] = start;
@@ -142,38 +183,48 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(MsmSegs segs, u
     }
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, segs.total);
-    uint32_t w_next[8];
-    if (lo + threadIdx.x < hi) load8(digits + 8ull * (lo + threadIdx.x), w_next);
+    uint32_t w_next[DW];
+    auto load_codes = [&](uint32_t idx, uint32_t* w) {
+        const uint2* src = reinterpret_cast<const uint2*>(digits + (size_t)DW * idx);
+#pragma unroll
+        for (int i = 0; i < DW / 2; ++i) { const uint2 v = src[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+    };
+    if (lo + threadIdx.x < hi) load_codes(lo + threadIdx.x, w_next);
     for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
         uint32_t ti;
         (void)seg_scalar(segs, idx, &ti);
-        uint32_t w[8];
+        uint32_t w[DW];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = w_next[i];
-        if (idx + SORT_THREADS < hi) load8(digits + 8ull * (idx + SORT_THREADS), w_next);   // in flight while these codes are placed
+        for (int i = 0; i < DW; ++i) w[i] = w_next[i];
+        if (idx + SORT_THREADS < hi) load_codes(idx + SORT_THREADS, w_next);   // in flight while these codes are placed
 #pragma unroll
-        for (int j = 0; j < MSM_WINDOWS; ++j) {
+        for (int j = 0; j < W; ++j) {
             const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
             if (code == DIGIT_NONE) continue;
             const uint32_t b = code & 0x7fffu;
-            const uint32_t slot = atomicAdd(&cursor[b >> 7], 1u);
+            const uint32_t slot = atomicAdd(&cursor[b >> SortPlan<C>::PART_BITS], 1u);
             const uint32_t entry = ((code & 0x8000u) << 16) | ((uint32_t)j * table_stride + ti);
-            records[slot] = (uint64_t)entry | ((uint64_t)(b & 127u) << 32);
+            records[slot] = (uint64_t)entry | ((uint64_t)(b & (SortPlan<C>::PART_BUCKETS - 1)) << 32);
         }
     }
 }
 // one workgroup per partition: bucket sizes, bucket starts, then the entries in bucket order.  T threads: 256 beside accumulation
 // kernels (a four-wave workgroup finds room on a busy CU), 1024 when the chip is idle (the first sort of a round: every CU has one
 // partition to itself and nothing else to do, so sixteen waves go through its records four times as fast).
-template <int T>
-__global__ void __launch_bounds__(T) k_sort_buckets(const uint64_t* __restrict__ records, const uint32_t* __restrict__ part_start,
-                                                    uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ entries) {
+template <int T, int C>
+__global__ void __launch_bounds__(T) k_sort_buckets(SortBatch sb) {
     PLK_SIDE_PRIO();
-    __shared__ uint32_t cnt[SORT_PART_BUCKETS];
+    constexpr int PB = SortPlan<C>::PART_BUCKETS, BUCKETS = MsmPlan<C>::BUCKETS;
+    const uint32_t mb = blockIdx.y;
+    const uint64_t* __restrict__ records = sb.records[mb];
+    const uint32_t* __restrict__ part_start = sb.part_start[mb];
+    uint32_t* __restrict__ bucket_start = sb.bucket_start[mb];
+    uint32_t* __restrict__ entries = sb.entries[mb];
+    __shared__ uint32_t cnt[PB];
     __shared__ uint32_t wave_sum[2];
     const uint32_t p = blockIdx.x, t = threadIdx.x;
     const uint32_t first = part_start[p], last = part_start[p + 1];
-    if (t < SORT_PART_BUCKETS) cnt[t] = 0;
+    if (t < PB) cnt[t] = 0;
     __syncthreads();
     // four records per thread and step, so that four loads are in flight instead of one
     for (uint32_t i = first + t; i < last; i += 4 * T) {
@@ -184,20 +235,20 @@ __global__ void __launch_bounds__(T) k_sort_buckets(const uint64_t* __restrict__
         for (int k = 0; k < 4; ++k) if (r[k] != ~0ull) atomicAdd(&cnt[(uint32_t)(r[k] >> 32)], 1u);
     }
     __syncthreads();
-    {                                   // exclusive scan of the 128 counters (the first two waves hold them)
-        const uint32_t lane = t & 63, wave = t >> 6, c = t < SORT_PART_BUCKETS ? cnt[t] : 0;
+    {                                   // exclusive scan of the counters (the first two waves hold them)
+        const uint32_t lane = t & 63, wave = t >> 6, c = t < PB ? cnt[t] : 0;
         uint32_t incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += x; }
         if (lane == 63 && wave < 2) wave_sum[wave] = incl;
         __syncthreads();
-        if (t < SORT_PART_BUCKETS) {
+        if (t < PB) {
             const uint32_t start = first + incl - c + (wave ? wave_sum[0] : 0);
-            bucket_start[p * SORT_PART_BUCKETS + t] = start;
+            bucket_start[p * PB + t] = start;
             cnt[t] = start;             // from here on: the next free slot of the bucket
         }
     }
-    if (p == SORT_PARTS - 1 && t == 0) bucket_start[MSM_BUCKETS] = last;
+    if (p == SORT_PARTS - 1 && t == 0) bucket_start[BUCKETS] = last;
     __syncthreads();
     for (uint32_t i = first + t; i < last; i += 4 * T) {
         uint64_t r[4];
@@ -228,21 +279,38 @@ __device__ __forceinline__ uint32_t acc_run_length(uint32_t n_entries, uint32_t 
     const uint32_t run = (n_entries + lanes_launched - 1) / lanes_launched;
     return run < 1 ? 1 : run;
 }
+// Members of a batch of accumulations: the workgroups [block_first[m], block_first[m + 1]) of the launch belong to member m.
+struct AccBatch {
+    const uint32_t* entries[MSM_SLOTS];
+    const uint32_t* bucket_start[MSM_SLOTS];
+    uint32_t* tails[MSM_SLOTS];
+    uint32_t* flushed[MSM_SLOTS];
+    uint32_t tail_stride[MSM_SLOTS];
+    uint32_t block_first[MSM_SLOTS + 1];
+    uint32_t n;
+};
 // Two waves per SIMD: the loop needs about 170 registers, and more resident waves were measured to add nothing (the kernel
 // is bound by VALU issue, not by latency).
+template <int BUCKETS>
 __global__ void __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ tables,
-                 uint32_t* __restrict__ tails, uint32_t tail_stride, uint32_t* __restrict__ flushed) {
-    const uint32_t lane = blockIdx.x * ACC_THREADS + threadIdx.x;
-    const uint32_t n_entries = bucket_start[MSM_BUCKETS];
-    const uint32_t run = acc_run_length(n_entries, gridDim.x * ACC_THREADS);
+k_msm_accumulate(AccBatch ab, const uint32_t* __restrict__ tables) {
+    uint32_t mb = 0;
+    while (mb + 1 < ab.n && blockIdx.x >= ab.block_first[mb + 1]) ++mb;
+    const uint32_t* __restrict__ entries = ab.entries[mb];
+    const uint32_t* __restrict__ bucket_start = ab.bucket_start[mb];
+    uint32_t* __restrict__ tails = ab.tails[mb];
+    uint32_t* __restrict__ flushed = ab.flushed[mb];
+    const uint32_t tail_stride = ab.tail_stride[mb];
+    const uint32_t lane = (blockIdx.x - ab.block_first[mb]) * ACC_THREADS + threadIdx.x;
+    const uint32_t n_entries = bucket_start[BUCKETS];
+    const uint32_t run = acc_run_length(n_entries, (ab.block_first[mb + 1] - ab.block_first[mb]) * ACC_THREADS);
     uint32_t e = lane * run;
     if (e >= n_entries) return;
     const uint32_t e_end = min(e + run, n_entries);
     // bucket of the first entry: the largest b with bucket_start[b] <= e (empty buckets share their start with the next one)
     uint32_t b = 0;
     {
-        uint32_t hi = MSM_BUCKETS;
+        uint32_t hi = BUCKETS;
         while (hi - b > 1) {
             const uint32_t mid = (b + hi) >> 1;
             if (bucket_start[mid] <= e) b = mid; else hi = mid;
@@ -326,20 +394,21 @@ struct ReduceBatch {
 };
 // bucket_sums[b] = flushed[b] (if the bucket ended inside a run) + the tails of all lanes whose run ended inside bucket b.
 // FOLD_LANES lanes per bucket share the tails, a shuffle tree joins them.
-template <int FOLD_LANES>
+template <int FOLD_LANES, int C>
 __device__ __forceinline__ void fold_body(const ReduceBatch& rb);
 // Two builds of every reduction kernel.  "side": held to 128 registers so that its waves fit beside two accumulation waves per SIMD
 // (they spill, which costs nothing that matters: these reductions run beside the accumulation kernels of later MSMs).
 // "tail": no register limit, for the reduction that ends a batch: nothing else is running then, and the round waits for it.
-template <int FOLD_LANES>
+template <int FOLD_LANES, int C>
 __global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(ReduceBatch rb) {
     PLK_SIDE_PRIO();
-    fold_body<FOLD_LANES>(rb);
+    fold_body<FOLD_LANES, C>(rb);
 }
-template <int FOLD_LANES>
-__global__ void __launch_bounds__(256) k_msm_fold_tail(ReduceBatch rb) { fold_body<FOLD_LANES>(rb); }
-template <int FOLD_LANES>
+template <int FOLD_LANES, int C>
+__global__ void __launch_bounds__(256) k_msm_fold_tail(ReduceBatch rb) { fold_body<FOLD_LANES, C>(rb); }
+template <int FOLD_LANES, int C>
 __device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
+    constexpr int BUCKETS = MsmPlan<C>::BUCKETS;
     const uint32_t* __restrict__ bucket_start = rb.bucket_start[blockIdx.y];
     const uint32_t* __restrict__ tails = rb.tails[blockIdx.y];
     const uint32_t* __restrict__ flushed = rb.flushed[blockIdx.y];
@@ -347,7 +416,7 @@ __device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
     uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t b = t / FOLD_LANES, j = t % FOLD_LANES;
-    const uint32_t first = bucket_start[b], last = bucket_start[b + 1], n_entries = bucket_start[MSM_BUCKETS];
+    const uint32_t first = bucket_start[b], last = bucket_start[b + 1], n_entries = bucket_start[BUCKETS];
     const uint32_t run = acc_run_length(n_entries, lanes_launched);
     xyzz acc = xyzz_inf();
     if (last > first) {
@@ -368,36 +437,47 @@ __device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
     if (j == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
 }
 
-// Output o of the 56 marginal sums: group d of the bucket index (bits [4d, 4d+4), the last group has 3 bits) equal to v.
-// Two kernels.  In the first every lane adds MARG_K buckets of one output one after the other and stores its sum: no lane idles in a
-// shuffle tree, so a batch of nine MSMs (2304 waves) costs the chip little more than one does.  The second joins the partial sums of an
-// output (256 of them, 512 for the outputs of the 3-bit group, which have twice the members): a few per lane, then one shuffle tree.
+// Marginal sums: output o = the sum of all buckets whose index has field d (bits [4d, 4d+4); the top field may be narrower) equal
+// to v.  Two kernels.  In the first every lane adds MARG_K buckets of one output one after the other and stores its sum: no lane
+// idles in a shuffle tree, so a batch of nine MSMs costs the chip little more than one does.  The second joins the partial sums of
+// an output: a few per lane, then one shuffle tree.
 constexpr int MARG_K = 8;
-constexpr int MARG_PART_A = (MSM_BUCKETS >> 4) / MARG_K, MARG_PART_B = (MSM_BUCKETS >> 3) / MARG_K;   // partial sums per output: 256, 512
-constexpr int MARG_PARTIALS = 48 * MARG_PART_A + 8 * MARG_PART_B;                                     // 16384 per MSM
-__device__ __forceinline__ void marginal_of(uint32_t o, uint32_t* d, uint32_t* v) { *d = o < 48 ? o >> 4 : 3; *v = o < 48 ? (o & 15) : o - 48; }
-__device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb);
-__device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb);
+template <int C>
+struct MargPlan {
+    using P = MsmPlan<C>;
+    static constexpr int NA = 16 * (P::FIELDS - 1), NB = 1 << P::LAST_BITS;                         // outputs of the 4-bit fields, of the top field
+    static constexpr int PART_A = (P::BUCKETS >> 4) / MARG_K, PART_B = (P::BUCKETS >> P::LAST_BITS) / MARG_K;   // partial sums per output
+    static constexpr int PARTIALS = NA * PART_A + NB * PART_B;                                       // 16384 | 1536 per MSM
+    static_assert(PARTIALS % 64 == 0, "whole waves");
+};
+constexpr int MARG_PARTIALS_MAX = MargPlan<MSM_C>::PARTIALS;
+template <int C> __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb);
+template <int C> __device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb);
+template <int C>
 __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(ReduceBatch rb) {
     PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
-    marginals_part_body(rb);
+    marginals_part_body<C>(rb);
 }
-__global__ void __launch_bounds__(64) k_msm_marginals_part_tail(ReduceBatch rb) { marginals_part_body(rb); }
+template <int C>
+__global__ void __launch_bounds__(64) k_msm_marginals_part_tail(ReduceBatch rb) { marginals_part_body<C>(rb); }
+template <int C>
 __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(ReduceBatch rb) {
     PLK_SIDE_PRIO();
-    marginals_join_body(rb);
+    marginals_join_body<C>(rb);
 }
-__global__ void __launch_bounds__(64) k_msm_marginals_join_tail(ReduceBatch rb) { marginals_join_body(rb); }
+template <int C>
+__global__ void __launch_bounds__(64) k_msm_marginals_join_tail(ReduceBatch rb) { marginals_join_body<C>(rb); }
+template <int C>
 __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb) {
+    using M = MargPlan<C>;
     const uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
     uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
-    const uint32_t lane_id = blockIdx.x * 64 + threadIdx.x;     // < MARG_PARTIALS
+    const uint32_t lane_id = blockIdx.x * 64 + threadIdx.x;     // < PARTIALS
     uint32_t o, p, stride;
-    if (lane_id < 48 * MARG_PART_A) { o = lane_id / MARG_PART_A; p = lane_id % MARG_PART_A; stride = MARG_PART_A; }
-    else { const uint32_t r = lane_id - 48 * MARG_PART_A; o = 48 + r / MARG_PART_B; p = r % MARG_PART_B; stride = MARG_PART_B; }
-    uint32_t d, v;
-    marginal_of(o, &d, &v);
-    const uint32_t shift = 4 * d, bits = d < 3 ? 4 : 3;
+    if (lane_id < M::NA * M::PART_A) { o = lane_id / M::PART_A; p = lane_id % M::PART_A; stride = M::PART_A; }
+    else { const uint32_t r = lane_id - M::NA * M::PART_A; o = M::NA + r / M::PART_B; p = r % M::PART_B; stride = M::PART_B; }
+    const uint32_t d = o < M::NA ? o >> 4 : MsmPlan<C>::FIELDS - 1, v = o < M::NA ? (o & 15) : o - M::NA;
+    const uint32_t shift = 4 * d, bits = o < M::NA ? 4 : MsmPlan<C>::LAST_BITS;
     xyzz acc = xyzz_inf();
 #pragma unroll 1
     for (int j = 0; j < MARG_K; ++j) {
@@ -407,11 +487,13 @@ __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb) {
     }
     st_xyzz(part + (size_t)lane_id * XYZZ_WORDS, acc);
 }
+template <int C>
 __device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb) {
+    using M = MargPlan<C>;
     const uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
     uint32_t* __restrict__ out = rb.marg_dev[blockIdx.y];
     const uint32_t o = blockIdx.x, lane = threadIdx.x;
-    const uint32_t first = o < 48 ? o * MARG_PART_A : 48 * MARG_PART_A + (o - 48) * MARG_PART_B, count = o < 48 ? MARG_PART_A : MARG_PART_B;
+    const uint32_t first = o < M::NA ? o * M::PART_A : M::NA * M::PART_A + (o - M::NA) * M::PART_B, count = o < M::NA ? M::PART_A : M::PART_B;
     xyzz acc = xyzz_inf();
 #pragma unroll 1
     for (uint32_t k = lane; k < count; k += 64) acc = xyzz_add(acc, ld_xyzz(part + (size_t)(first + k) * XYZZ_WORDS));
@@ -446,12 +528,12 @@ __device__ __forceinline__ void store_affine_of(const xyzz& a, uint32_t* dst) {
     st_fe<FqP>(dst, mul<FqP>(a.x, mul<FqP>(i, a.zzz)));
     st_fe<FqP>(dst + 8, mul<FqP>(a.y, mul<FqP>(i, a.zz)));
 }
-// next[i] = 2^16 * prev[i]
-__global__ void __launch_bounds__(256) k_table_next(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, uint64_t count) {
+// next[i] = 2^doublings * prev[i]
+__global__ void __launch_bounds__(256) k_table_next(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, uint64_t count, int doublings) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     xyzz a = xyzz_dbl_affine(load_aff(prev + 16 * i));
-    for (int k = 1; k < MSM_C; ++k) a = xyzz_dbl(a);
+    for (int k = 1; k < doublings; ++k) a = xyzz_dbl(a);
     store_affine_of(a, next + 16 * i);
 }
 // dst[i] = scale * tau^(first + i) * G through 8-bit fixed-base windows of G: gt[w][d] = d * 2^(8 w) * G.
@@ -479,6 +561,11 @@ __global__ void __launch_bounds__(256) k_srs_generate(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------ host side
 static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     if (s.ready) return PLK_OK;
+    if (!ctx->marg_all_dev) {
+        PLK_HIP(hipMalloc(&ctx->marg_all_dev, (size_t)MSM_SLOTS * MSM_MARGINALS * 32 * 4));
+        PLK_HIP(hipHostMalloc(&ctx->marg_all_host, (size_t)MSM_SLOTS * MSM_MARGINALS * 32 * 4, hipHostMallocDefault));
+    }
+    const size_t idx = (size_t)(&s - ctx->slot);
     PLK_HIP(hipEventCreateWithFlags(&s.sorted, hipEventDisableTiming));
     PLK_HIP(hipEventCreateWithFlags(&s.accumulated, hipEventDisableTiming));
     PLK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -487,9 +574,9 @@ static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     PLK_HIP(hipMalloc(&s.bucket_start, (size_t)(MSM_BUCKETS + 1) * 4));
     PLK_HIP(hipMalloc(&s.bucket_sums, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
     PLK_HIP(hipMalloc(&s.flushed, (size_t)MSM_BUCKETS * XYZZ_WORDS * 4));
-    PLK_HIP(hipMalloc(&s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4));
-    PLK_HIP(hipMalloc(&s.marg_part, (size_t)MARG_PARTIALS * XYZZ_WORDS * 4));
-    PLK_HIP(hipHostMalloc(&s.marg_host, (size_t)MSM_MARGINALS * 32 * 4, hipHostMallocDefault));
+    s.marg_dev = ctx->marg_all_dev + idx * MSM_MARGINALS * 32;       // slices of the context's arrays: not freed with the slot
+    s.marg_host = ctx->marg_all_host + idx * MSM_MARGINALS * 32;
+    PLK_HIP(hipMalloc(&s.marg_part, (size_t)MARG_PARTIALS_MAX * XYZZ_WORDS * 4));
     PLK_HIP(hipMalloc(&s.blind_dev, 64 * 4));
     PLK_HIP(hipHostMalloc(&s.blind_host, 64 * 4, hipHostMallocDefault));
     PLK_HIP(hipMalloc(&s.res_dev, 64 * 4));
@@ -524,12 +611,14 @@ static int32_t tails_reserve(plk_ctx* ctx, MsmSlot& s, uint64_t lanes) {
 // synchronisation) happens while proofs are running.
 static int32_t slots_reserve(plk_ctx* ctx) {
     const uint64_t max_scalars = ctx->shard_len + 3;
-    const uint64_t entries = max_scalars * MSM_WINDOWS + 1024;   // a multiple of 16: the digit codes behind the entries are stored 16 bytes at a time
+    uint64_t entries = max_scalars * MsmPlan<MSM_C>::WINDOWS;
+    if (ctx->tables_short) entries = std::max<uint64_t>(entries, (std::min<uint64_t>(ctx->shard_len, ctx->short_len) + 3) * MsmPlan<MSM_C_SHORT>::WINDOWS);
+    entries = (entries + 1024 + 15) & ~15ull;   // a multiple of 16: the digit codes behind the entries are stored 16 bytes at a time
     const uint64_t scal_words = (ctx->srs_total + 1) * 8, chain_words = division_work_words(ctx->srs_total);
     for (auto& s : ctx->slot) {
         PLK_TRY(slot_init(ctx, s));
         if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 14)); s.entries_cap = entries; }   // per entry: 4 bytes sorted entry + 2 digit code + 8 record of the two-level sort
-        PLK_TRY(tails_reserve(ctx, s, acc_lanes(entries, acc_run(entries))));
+        PLK_TRY(tails_reserve(ctx, s, acc_lanes(entries, 16)));
         if (s.scal_cap < scal_words) { if (s.scal_dev) PLK_HIP(hipFree(s.scal_dev)); s.scal_dev = nullptr; s.scal_cap = 0; PLK_HIP(hipMalloc(&s.scal_dev, scal_words * 4)); s.scal_cap = scal_words; }
         if (s.chain_cap < chain_words) { if (s.chain_dev) PLK_HIP(hipFree(s.chain_dev)); s.chain_dev = nullptr; s.chain_cap = 0; PLK_HIP(hipMalloc(&s.chain_dev, chain_words * 4)); s.chain_cap = chain_words; }
     }
@@ -537,8 +626,8 @@ static int32_t slots_reserve(plk_ctx* ctx) {
 }
 void slot_destroy(MsmSlot& s) {
     if (!s.ready) return;
-    hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.flushed); hipFree(s.tails); hipFree(s.marg_dev); hipFree(s.marg_part);
-    hipHostFree(s.marg_host); hipFree(s.blind_dev); hipHostFree(s.blind_host); hipFree(s.scal_dev); hipFree(s.chain_dev);
+    hipFree(s.counts); hipFree(s.totals); hipFree(s.bucket_start); hipFree(s.entries); hipFree(s.bucket_sums); hipFree(s.flushed); hipFree(s.tails); hipFree(s.marg_part);
+    hipFree(s.blind_dev); hipHostFree(s.blind_host); hipFree(s.scal_dev); hipFree(s.chain_dev);
     hipFree(s.res_dev); hipHostFree(s.res_host);
     hipEventDestroy(s.sorted); hipEventDestroy(s.accumulated); hipEventDestroy(s.done);
     s = MsmSlot();
@@ -584,6 +673,14 @@ static void clip_to_shard(const plk_ctx* ctx, const uint32_t* scalars, uint64_t 
     seg->count = (uint32_t)(hi - lo);
     seg->table_off = (uint32_t)(lo - slo);
 }
+// Window width for the MSM over the global range [base_offset, base_offset + k): the narrow plan when this rank's share is short
+// and lies inside the prefix of the SRS that the narrow tables cover.
+int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset) {
+    if (!ctx->tables_short || base_offset + k > ctx->srs_total) return MSM_C;
+    MsmSeg seg;
+    clip_to_shard(ctx, nullptr, k, base_offset, &seg);
+    return (seg.count <= ctx->short_max && (uint64_t)seg.table_off + seg.count <= ctx->short_len) ? MSM_C_SHORT : MSM_C;
+}
 
 // The stream for the front work (division, sort) of the next job: consecutive jobs alternate between the compute stream and the
 // reduction stream, so that the sort of one runs beside the division or sort of the next (0.2-0.3 ms per proof of 2^20 gates
@@ -593,166 +690,265 @@ hipStream_t front_lane(plk_ctx* ctx) {
     if (ctx->detached || ctx->uploads_pending) return ctx->st_sort;
     return (ctx->lane_turn++ & 1) ? ctx->st_red : ctx->st_sort;
 }
-// Enqueues one MSM: main segment (device scalars over powers_of_g) plus, when n_blind > 0 and this shard holds the gamma powers,
-// n_blind scalars (already in slot.blind_dev) over powers_of_gamma_g.  The sort goes to `lane` (st_sort when null).
-int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind, hipStream_t lane, int idle_hint,
-                    const uint32_t* blind_dev) {
+
+template <int C>
+static void launch_sort(hipStream_t st, const SortBatch& sb, uint32_t max_blocks, uint32_t n, bool fast) {
+    hipLaunchKernelGGL(k_sort_digits_count<C>, dim3(max_blocks, n), dim3(SORT_THREADS), 0, st, sb);
+    hipLaunchKernelGGL(k_sort_partition<C>, dim3(max_blocks, n), dim3(SORT_THREADS), 0, st, sb);
+    if (fast) hipLaunchKernelGGL((k_sort_buckets<1024, C>), dim3(SORT_PARTS, n), dim3(1024), 0, st, sb);
+    else hipLaunchKernelGGL((k_sort_buckets<SORT_THREADS, C>), dim3(SORT_PARTS, n), dim3(SORT_THREADS), 0, st, sb);
+}
+// Enqueues the MSMs of `n` jobs that share their launches (one sort, one accumulation; their reductions are batched by
+// msm_flush_reductions anyway) and one window plan.  Per job: the main segment (device scalars over powers_of_g) plus, when
+// n_blind > 0 and this shard holds the gamma powers, n_blind scalars over powers_of_gamma_g.  The sort goes to `lane`.
+int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStream_t lane, int idle_hint, int plan_c) {
     if (!ctx->tables) { ctx->err = "no SRS loaded"; return PLK_ERR_INVALID_ARG; }
-    if (base_offset + k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
-    MsmSegs segs;
-    clip_to_shard(ctx, scalars_dev, k, base_offset, &segs.s[0]);
-    segs.s[1].scalars = blind_dev ? blind_dev : s.blind_dev;
-    segs.s[1].count = ctx->has_gamma ? n_blind : 0;
-    segs.s[1].table_off = (uint32_t)ctx->shard_len;
-    segs.s[1].world = 1; segs.s[1].rank = 0; segs.s[1].log_block = 0; segs.s[1].origin = 0;
-    segs.nseg = 2;
-    segs.total = segs.s[0].count + segs.s[1].count;
-    const uint64_t max_entries = (uint64_t)segs.total * MSM_WINDOWS;
-    if (max_entries > s.entries_cap) {   // the slot is idle here: its previous job was waited for before it was handed out again
-        if (s.entries) PLK_HIP(hipFree(s.entries));
-        s.entries = nullptr; s.entries_cap = 0;
-        const uint64_t cap = (max_entries + max_entries / 8 + 1024 + 15) & ~15ull;   // the digit codes behind the entries are stored 16 bytes at a time
-        PLK_HIP(hipMalloc(&s.entries, cap * 14));   // 4 bytes per entry + 2 per digit code + 8 per record
-        s.entries_cap = cap;
-    }
-    PLK_TRY(tails_reserve(ctx, s, acc_lanes(max_entries, acc_run(max_entries))));
+    if (n == 0 || n > (uint32_t)MSM_SLOTS) return PLK_ERR_INVALID_ARG;
+    const bool narrow = plan_c == MSM_C_SHORT;
+    if (narrow && !ctx->tables_short) { ctx->err = "narrow window plan without its tables"; return PLK_ERR_INVALID_ARG; }
+    const uint32_t windows = narrow ? MsmPlan<MSM_C_SHORT>::WINDOWS : MsmPlan<MSM_C>::WINDOWS;
+    const uint32_t buckets = narrow ? MsmPlan<MSM_C_SHORT>::BUCKETS : MsmPlan<MSM_C>::BUCKETS;
     hipStream_t st = lane ? lane : ctx->st_sort;
     bool idle = ctx->reduce_pending.empty();   // nothing of this context is running or queued on the device
-    for (const auto& other : ctx->slot) idle = idle && (!other.busy || &other == &s);
+    for (const auto& other : ctx->slot) {
+        bool mine = false;
+        for (uint32_t m = 0; m < n; ++m) mine = mine || &other == &ctx->slot[jobs[m].slot];
+        idle = idle && (!other.busy || mine);
+    }
     if (idle_hint >= 0) idle = idle_hint != 0;   // a batch marks all its slots busy before it enqueues the first
-    prof_begin(ctx, st, "msm_sort");
-    uint32_t* digits = s.entries + s.entries_cap;      // 16 two-byte codes per scalar, at most entries_cap of them
-    {
-        uint64_t* records = reinterpret_cast<uint64_t*>(s.entries + s.entries_cap + s.entries_cap / 2);
-        // Raised issue priority for every sort: given to the first four sorts of a round only, the later ones take twice as long, the
-        // accumulation kernels 3 % less, and the proof the same or 0.1 ms more; to the first two only, 1.7 ms more.
-        // 8192 scalars per workgroup (pieces of 512 records per partition), down to 1024 for short MSMs, never more than 512 workgroups
-        // (every workgroup of the partitioning kernel reads the whole count matrix).  Measured inside a proof of 2^20 gates: 4096 scalars
-        // per workgroup the same, 16384 0.6 ms slower; four workgroups per partition in the second level (1024 workgroups, two launches)
-        // halve the isolated sort and make the proof 0.7 ms slower; without the raised issue priority 0.9 ms slower.
-        // The first sort of a round finds the chip idle and the round waiting for it: four times as many workgroups in the first level
-        // (two per CU at 2^20 scalars; 0.1 ms per proof better than twice as many, workgroups of 512 or 1024 threads instead: no better),
-        // sixteen waves per partition in the second (0.2 ms per proof).
-        const bool fast = idle;
+    SortBatch sb;
+    memset(&sb, 0, sizeof(sb));
+    sb.table_stride = (uint32_t)(narrow ? ctx->short_stride : ctx->table_stride);
+    uint64_t max_entries[MSM_SLOTS], total_entries = 0;
+    uint32_t max_blocks = 1;
+    // Raised issue priority for every sort: given to the first four sorts of a round only, the later ones take twice as long, the
+    // accumulation kernels 3 % less, and the proof the same or 0.1 ms more; to the first two only, 1.7 ms more.
+    // 8192 scalars per workgroup (pieces of 512 records per partition), down to 1024 for short MSMs, never more than 512 workgroups
+    // (every workgroup of the partitioning kernel reads the whole count matrix).  Measured inside a proof of 2^20 gates: 4096 scalars
+    // per workgroup the same, 16384 0.6 ms slower; four workgroups per partition in the second level (1024 workgroups, two launches)
+    // halve the isolated sort and make the proof 0.7 ms slower; without the raised issue priority 0.9 ms slower.
+    // The first sort of a round finds the chip idle and the round waiting for it: four times as many workgroups in the first level
+    // (two per CU at 2^20 scalars; 0.1 ms per proof better than twice as many, workgroups of 512 or 1024 threads instead: no better),
+    // sixteen waves per partition in the second (0.2 ms per proof).
+    const bool fast = idle;
+    for (uint32_t m = 0; m < n; ++m) {
+        const MsmJob& j = jobs[m];
+        MsmSlot& s = ctx->slot[j.slot];
+        if (j.base_offset + j.k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
+        MsmSegs& segs = sb.segs[m];
+        clip_to_shard(ctx, j.scalars, j.k, j.base_offset, &segs.s[0]);
+        if (narrow && ((uint64_t)segs.s[0].table_off + segs.s[0].count > ctx->short_len)) { ctx->err = "MSM outside the prefix of the narrow tables"; return PLK_ERR_INVALID_ARG; }
+        segs.s[1].scalars = j.blind_dev ? j.blind_dev : s.blind_dev;
+        segs.s[1].count = ctx->has_gamma ? j.n_blind : 0;
+        segs.s[1].table_off = (uint32_t)(narrow ? ctx->short_len : ctx->shard_len);
+        segs.s[1].world = 1; segs.s[1].rank = 0; segs.s[1].log_block = 0; segs.s[1].origin = 0;
+        segs.nseg = 2;
+        segs.total = segs.s[0].count + segs.s[1].count;
+        max_entries[m] = (uint64_t)segs.total * windows;
+        total_entries += max_entries[m];
+        if (max_entries[m] > s.entries_cap) {   // the slot is idle here: its previous job was waited for before it was handed out again
+            if (s.entries) PLK_HIP(hipFree(s.entries));
+            s.entries = nullptr; s.entries_cap = 0;
+            const uint64_t cap = (max_entries[m] + max_entries[m] / 8 + 1024 + 15) & ~15ull;   // the digit codes behind the entries are stored 16 bytes at a time
+            PLK_HIP(hipMalloc(&s.entries, cap * 14));   // 4 bytes per entry + 2 per digit code + 8 per record
+            s.entries_cap = cap;
+        }
         uint32_t per = fast ? 2048 : 8192;
         while (per > 1024 && (segs.total + per - 1) / per < 128) per >>= 1;
         uint32_t nb = (segs.total + per - 1) / per;
         if (nb < 1) nb = 1;
         if (nb > (uint32_t)SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
-        const uint32_t ch = (segs.total + nb - 1) / nb;
-        uint32_t* part_start = s.totals;               // SORT_PARTS + 1 words (the buffer holds MSM_BUCKETS)
-        hipLaunchKernelGGL(k_sort_digits_count, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts);
-        PLK_TRY(lane_read_mark(ctx, st));          // the last reader of the caller's scalars
-        hipLaunchKernelGGL(k_sort_partition, dim3(nb), dim3(SORT_THREADS), 0, st, segs, ch, digits, s.counts, nb, part_start, (uint32_t)ctx->table_stride, records);
-        if (fast) hipLaunchKernelGGL(k_sort_buckets<1024>, dim3(SORT_PARTS), dim3(1024), 0, st, records, part_start, s.bucket_start, s.entries);
-        else hipLaunchKernelGGL(k_sort_buckets<SORT_THREADS>, dim3(SORT_PARTS), dim3(SORT_THREADS), 0, st, records, part_start, s.bucket_start, s.entries);
+        sb.nblocks[m] = nb;
+        sb.chunk[m] = (segs.total + nb - 1) / nb;
+        sb.digits[m] = s.entries + s.entries_cap;      // two-byte codes, at most entries_cap of them
+        sb.records[m] = reinterpret_cast<uint64_t*>(s.entries + s.entries_cap + s.entries_cap / 2);
+        sb.counts[m] = s.counts;
+        sb.part_start[m] = s.totals;                   // SORT_PARTS + 1 words (the buffer holds MSM_BUCKETS)
+        sb.bucket_start[m] = s.bucket_start;
+        sb.entries[m] = s.entries;
+        max_blocks = std::max(max_blocks, nb);
     }
+    // run length of the accumulation from the whole group: together the members should fill the chip a whole number of times
+    uint32_t run = acc_run(total_entries);
+    if (narrow) { static const uint32_t min_run = getenv("PLK_NARROW_MIN_RUN") ? (uint32_t)atoi(getenv("PLK_NARROW_MIN_RUN")) : 16; run = std::max(run, min_run); }
+    AccBatch ab;
+    memset(&ab, 0, sizeof(ab));
+    ab.n = n;
+    uint32_t blocks_so_far = 0;
+    for (uint32_t m = 0; m < n; ++m) {
+        MsmSlot& s = ctx->slot[jobs[m].slot];
+        const uint64_t lanes = acc_lanes(max_entries[m], run);
+        PLK_TRY(tails_reserve(ctx, s, lanes));
+        const uint32_t blocks = (uint32_t)((lanes + ACC_THREADS - 1) / ACC_THREADS);
+        ab.entries[m] = s.entries; ab.bucket_start[m] = s.bucket_start; ab.tails[m] = s.tails; ab.flushed[m] = s.flushed;
+        ab.tail_stride[m] = (uint32_t)s.tail_cap;
+        ab.block_first[m] = blocks_so_far;
+        blocks_so_far += blocks;
+        s.acc_blocks = blocks;
+    }
+    for (uint32_t m = n; m <= (uint32_t)MSM_SLOTS; ++m) ab.block_first[m] = blocks_so_far;
+    MsmSlot& leader = ctx->slot[jobs[0].slot];
+    prof_begin(ctx, st, "msm_sort");
+    if (narrow) launch_sort<MSM_C_SHORT>(st, sb, max_blocks, n, fast);
+    else launch_sort<MSM_C>(st, sb, max_blocks, n, fast);
     prof_end(ctx, st);
-    PLK_HIP(hipEventRecord(s.sorted, st));
+    PLK_TRY(lane_read_mark(ctx, st));          // the digit kernel is the last reader of the callers' scalars; the mark covers the whole sort
+    PLK_HIP(hipEventRecord(leader.sorted, st));
     // The accumulation goes to the stream with less work queued (entries of the jobs enqueued since the device was last idle): the kernel
     // behind a long one would otherwise wait for it to drain completely while the other stream has nothing left to run.
     if (idle) ctx->acc_load[0] = ctx->acc_load[1] = 0;
     const int acc_stream = ctx->acc_load[1] < ctx->acc_load[0] ? 1 : 0;
-    ctx->acc_load[acc_stream] += max_entries + 65536;   // a launch costs something even when it is empty
+    ctx->acc_load[acc_stream] += total_entries + 65536;   // a launch costs something even when it is empty
     st = ctx->st_acc[acc_stream];
-    PLK_HIP(hipStreamWaitEvent(st, s.sorted, 0));
-    const uint32_t acc_blocks = (uint32_t)((acc_lanes(max_entries, acc_run(max_entries)) + ACC_THREADS - 1) / ACC_THREADS);
+    PLK_HIP(hipStreamWaitEvent(st, leader.sorted, 0));
     prof_begin(ctx, st, "msm_accumulate");
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(ACC_THREADS), 0, st, s.entries, s.bucket_start, ctx->tables, s.tails, (uint32_t)s.tail_cap, s.flushed);
+    const uint32_t* tables = narrow ? ctx->tables_short : ctx->tables;
+    if (narrow) hipLaunchKernelGGL(k_msm_accumulate<MsmPlan<MSM_C_SHORT>::BUCKETS>, dim3(blocks_so_far), dim3(ACC_THREADS), 0, st, ab, tables);
+    else hipLaunchKernelGGL(k_msm_accumulate<MsmPlan<MSM_C>::BUCKETS>, dim3(blocks_so_far), dim3(ACC_THREADS), 0, st, ab, tables);
     prof_end(ctx, st);
-    PLK_HIP(hipEventRecord(s.accumulated, st));
-    s.max_entries = max_entries;
-    s.acc_stream = acc_stream;
-    s.acc_blocks = acc_blocks;
-    ctx->reduce_pending.push_back((int)(&s - ctx->slot));
+    PLK_HIP(hipEventRecord(leader.accumulated, st));
+    (void)buckets;
+    for (uint32_t m = 0; m < n; ++m) {
+        MsmSlot& s = ctx->slot[jobs[m].slot];
+        s.max_entries = max_entries[m];
+        s.acc_stream = acc_stream;
+        s.plan_c = plan_c;
+        s.ev_owner = jobs[0].slot;
+        s.done_owner = jobs[m].slot;
+        ctx->reduce_pending.push_back(jobs[m].slot);
+    }
     PLK_HIP(hipGetLastError());
     return PLK_OK;
+}
+int32_t msm_enqueue(plk_ctx* ctx, MsmSlot& s, const uint32_t* scalars_dev, uint64_t k, uint64_t base_offset, uint32_t n_blind, hipStream_t lane, int idle_hint,
+                    const uint32_t* blind_dev) {
+    if (!ctx->tables) { ctx->err = "no SRS loaded"; return PLK_ERR_INVALID_ARG; }
+    if (base_offset + k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
+    MsmJob j;
+    j.slot = (int)(&s - ctx->slot); j.scalars = scalars_dev; j.k = k; j.base_offset = base_offset; j.n_blind = n_blind; j.blind_dev = blind_dev;
+    return msm_enqueue_group(ctx, &j, 1, lane, idle_hint, msm_plan_for(ctx, k, base_offset));
 }
 
 // The reduction stream is a queue: a reduction that waits for a long accumulation holds up every reduction behind it, also those
 // whose accumulation finished long ago.  Reductions are therefore not enqueued with their MSM but when the first result of a
 // batch is asked for, in the order in which the accumulations are expected to finish (two streams, taken alternately, each
 // kernel's time proportional to its entries).
+template <int C>
+static void launch_reduction(hipStream_t st, const ReduceBatch& rb, uint64_t tails_per_bucket, bool tail) {
+    constexpr int BUCKETS = MsmPlan<C>::BUCKETS, PARTIALS = MargPlan<C>::PARTIALS, OUTPUTS = MsmPlan<C>::MARGINALS;
+    // runs that end inside an average bucket; two lanes per bucket keep the fold cheap, more lanes keep its serial chain short
+    if (tail) {
+        // the batch ends with this reduction: all registers, no spills
+        if (tails_per_bucket <= 12) hipLaunchKernelGGL((k_msm_fold_tail<2, C>), dim3(BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
+        else if (tails_per_bucket <= 48) hipLaunchKernelGGL((k_msm_fold_tail<4, C>), dim3(BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
+        else hipLaunchKernelGGL((k_msm_fold_tail<8, C>), dim3(BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_part_tail<C>, dim3(PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_join_tail<C>, dim3(OUTPUTS, rb.n), dim3(64), 0, st, rb);
+    } else {
+        if (tails_per_bucket <= 12) hipLaunchKernelGGL((k_msm_fold<2, C>), dim3(BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
+        else if (tails_per_bucket <= 48) hipLaunchKernelGGL((k_msm_fold<4, C>), dim3(BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
+        else hipLaunchKernelGGL((k_msm_fold<8, C>), dim3(BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_part<C>, dim3(PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
+        hipLaunchKernelGGL(k_msm_marginals_join<C>, dim3(OUTPUTS, rb.n), dim3(64), 0, st, rb);
+    }
+}
 static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group, bool tail) {
     hipStream_t st = ctx->st_red;
     ReduceBatch rb;
     memset(&rb, 0, sizeof(rb));
     rb.n = (int32_t)group.size();
+    const int plan_c = ctx->slot[group[0]].plan_c;
+    const uint64_t buckets = plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::BUCKETS : MsmPlan<MSM_C>::BUCKETS;
     uint64_t tails_per_bucket = 0;
+    int waited = -1, lo = MSM_SLOTS, hi = -1;
     for (int i = 0; i < rb.n; ++i) {
         MsmSlot& s = ctx->slot[group[i]];
-        PLK_HIP(hipStreamWaitEvent(st, s.accumulated, 0));
+        if (s.ev_owner != waited) { PLK_HIP(hipStreamWaitEvent(st, ctx->slot[s.ev_owner].accumulated, 0)); waited = s.ev_owner; }   // members of a batch share one event
         rb.bucket_start[i] = s.bucket_start; rb.tails[i] = s.tails; rb.flushed[i] = s.flushed;
         rb.tail_stride[i] = (uint32_t)s.tail_cap; rb.lanes_launched[i] = s.acc_blocks * ACC_THREADS;
         rb.bucket_sums[i] = s.bucket_sums; rb.marg_part[i] = s.marg_part; rb.marg_dev[i] = s.marg_dev;
-        tails_per_bucket = std::max<uint64_t>(tails_per_bucket, (uint64_t)s.acc_blocks * ACC_THREADS / MSM_BUCKETS);
+        tails_per_bucket = std::max<uint64_t>(tails_per_bucket, (uint64_t)s.acc_blocks * ACC_THREADS / buckets);
+        lo = std::min(lo, group[i]); hi = std::max(hi, group[i]);
     }
     prof_begin(ctx, st, "msm_reduce");
-    // runs that end inside an average bucket; two lanes per bucket keep the fold cheap, more lanes keep its serial chain short
-    if (tail) {
-        // the batch ends with this reduction: all registers, no spills
-        if (tails_per_bucket <= 12) hipLaunchKernelGGL(k_msm_fold_tail<2>, dim3(MSM_BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
-        else if (tails_per_bucket <= 48) hipLaunchKernelGGL(k_msm_fold_tail<4>, dim3(MSM_BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
-        else hipLaunchKernelGGL(k_msm_fold_tail<8>, dim3(MSM_BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
-        hipLaunchKernelGGL(k_msm_marginals_part_tail, dim3(MARG_PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
-        hipLaunchKernelGGL(k_msm_marginals_join_tail, dim3(MSM_MARGINALS, rb.n), dim3(64), 0, st, rb);
-    } else {
-        if (tails_per_bucket <= 12) hipLaunchKernelGGL(k_msm_fold<2>, dim3(MSM_BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
-        else if (tails_per_bucket <= 48) hipLaunchKernelGGL(k_msm_fold<4>, dim3(MSM_BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
-        else hipLaunchKernelGGL(k_msm_fold<8>, dim3(MSM_BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
-        hipLaunchKernelGGL(k_msm_marginals_part, dim3(MARG_PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
-        hipLaunchKernelGGL(k_msm_marginals_join, dim3(MSM_MARGINALS, rb.n), dim3(64), 0, st, rb);
-    }
+    if (plan_c == MSM_C_SHORT) launch_reduction<MSM_C_SHORT>(st, rb, tails_per_bucket, tail);
+    else launch_reduction<MSM_C>(st, rb, tails_per_bucket, tail);
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
-    for (int i = 0; i < rb.n; ++i) {
-        MsmSlot& s = ctx->slot[group[i]];
-        PLK_HIP(hipMemcpyAsync(s.marg_host, s.marg_dev, (size_t)MSM_MARGINALS * 32 * 4, hipMemcpyDeviceToHost, st));
-        PLK_HIP(hipEventRecord(s.done, st));
-    }
+    // One copy brings back the outputs of the whole launch: the slots' output arrays lie side by side.  Slots between the first and
+    // the last of the group that belong to other jobs are copied as well: their device and host contents are equal at this point
+    // (a slot's outputs change only in its own reduction, which is followed by its own copy on this same stream).
+    const size_t slice = (size_t)MSM_MARGINALS * 32;
+    PLK_HIP(hipMemcpyAsync(ctx->marg_all_host + lo * slice, ctx->marg_all_dev + lo * slice, (size_t)(hi - lo + 1) * slice * 4, hipMemcpyDeviceToHost, st));
+    PLK_HIP(hipEventRecord(ctx->slot[group[0]].done, st));
+    for (int i = 0; i < rb.n; ++i) ctx->slot[group[i]].done_owner = group[0];
     return PLK_OK;
 }
 int32_t msm_flush_reductions(plk_ctx* ctx) {
     if (ctx->reduce_pending.empty()) return PLK_OK;
     std::vector<std::pair<double, int>> order;
     double stream_free[2] = {0, 0};
+    int last_owner = -1;
     for (int si : ctx->reduce_pending) {
         const MsmSlot& s = ctx->slot[si];
-        stream_free[s.acc_stream] += (double)s.max_entries + 65536.0;   // a launch costs something even when it is empty
+        // the members of a batch finish together: their launch is counted once, with the entries of all of them
+        if (s.ev_owner != last_owner) {
+            double group_entries = 0;
+            for (int sj : ctx->reduce_pending) if (ctx->slot[sj].ev_owner == s.ev_owner) group_entries += (double)ctx->slot[sj].max_entries;
+            stream_free[s.acc_stream] += group_entries + 65536.0;   // a launch costs something even when it is empty
+            last_owner = s.ev_owner;
+        }
         order.push_back({stream_free[s.acc_stream], si});
     }
     ctx->reduce_pending.clear();
     std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
-    // neighbours in that order share a launch as long as their accumulations together take well under a millisecond
+    // neighbours in that order share a launch as long as their accumulations together take well under a millisecond (and they use
+    // the same window plan: a launch is compiled for one bucket count)
     constexpr uint64_t GROUP_ENTRIES = 12ull << 20;
-    std::vector<int> group;
-    uint64_t group_entries = 0;
-    for (const auto& o : order) {
-        const uint64_t e = ctx->slot[o.second].max_entries;
-        if (!group.empty() && group_entries + e > GROUP_ENTRIES) {
-            PLK_TRY(enqueue_reduction(ctx, group, false));
-            group.clear(); group_entries = 0;
+    struct Group { std::vector<int> slots; uint64_t entries = 0; double finish = 0; };
+    std::vector<Group> all;
+    // the two window plans form their groups separately (a two-coefficient polynomial on the narrow plan must not cut a run of
+    // long MSMs on the wide plan into two launches); the groups are then taken in the order in which their last members finish
+    for (int plan : {MSM_C, MSM_C_SHORT}) {
+        bool open = false;
+        for (const auto& o : order) {
+            if (ctx->slot[o.second].plan_c != plan) continue;
+            const uint64_t e = ctx->slot[o.second].max_entries;
+            if (!open || all.back().entries + e > GROUP_ENTRIES) { all.emplace_back(); open = true; }
+            all.back().slots.push_back(o.second);
+            all.back().entries += e;
+            all.back().finish = o.first;
         }
-        group.push_back(o.second);
-        group_entries += e;
     }
-    if (!group.empty()) PLK_TRY(enqueue_reduction(ctx, group, true));   // the last group to finish ends the batch
+    std::stable_sort(all.begin(), all.end(), [](const Group& x, const Group& y) { return x.finish < y.finish; });
+    std::vector<std::vector<int>> groups;
+    std::vector<uint64_t> entries_of;
+    for (auto& g : all) { groups.push_back(g.slots); entries_of.push_back(g.entries); }
+    // The last group to finish ends the batch and gets the builds without a register limit: nothing else is running then.  So does a
+    // group that is followed by next to nothing (the handful of entries of a two-coefficient polynomial, which sit in a group of
+    // their own when they use the other window plan): the accumulations behind it are over before its reduction has started.
+    uint64_t later = 0;
+    std::vector<bool> tail(groups.size(), false);
+    for (size_t g = groups.size(); g-- > 0;) { tail[g] = later < (1ull << 16); later += entries_of[g]; }
+    for (size_t g = 0; g < groups.size(); ++g) PLK_TRY(enqueue_reduction(ctx, groups[g], tail[g]));
     return PLK_OK;
 }
 
-// Host tail: sum_k k*B_k from the 56 marginal sums.  weight of bucket index idx is idx + 1.
-void msm_host_tail(const uint32_t* marg, host::pt* out) {
+// Host tail: sum_k k*B_k from the marginal sums.  weight of bucket index idx is idx + 1.
+void msm_host_tail(const uint32_t* marg, int plan_c, host::pt* out) {
     using namespace host;
     const uint64_t* m = reinterpret_cast<const uint64_t*>(marg);
     auto M = [&](int o) { return pt_load(m + 16 * o); };
+    const int fields = plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::FIELDS : MsmPlan<MSM_C>::FIELDS;
+    const int last_bits = plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::LAST_BITS : MsmPlan<MSM_C>::LAST_BITS;
     pt total = pt_inf();
-    for (int v = 0; v < 16; ++v) total = pt_add(total, M(v));          // sum of all buckets (the "+1")
+    for (int v = 0; v < 16; ++v) total = pt_add(total, M(v));          // sum of all buckets (the "+1"): every bucket has exactly one value in field 0
     pt acc = pt_inf();
-    for (int d = 3; d >= 0; --d) {
-        const int nv = d < 3 ? 16 : 8, base = d < 3 ? 16 * d : 48;
+    for (int d = fields - 1; d >= 0; --d) {
+        const int nv = d < fields - 1 ? 16 : (1 << last_bits), base = 16 * d;
         pt run = pt_inf(), s = pt_inf();
         for (int v = nv - 1; v >= 1; --v) { run = pt_add(run, M(base + v)); s = pt_add(s, run); }
-        if (d < 3) for (int k = 0; k < 4; ++k) acc = pt_dbl(acc);    // the group above sits 4 bits higher
+        if (d < fields - 1) for (int k = 0; k < 4; ++k) acc = pt_dbl(acc);    // the field above sits 4 bits higher
         acc = pt_add(acc, s);
     }
     *out = pt_add(acc, total);
@@ -760,8 +956,8 @@ void msm_host_tail(const uint32_t* marg, host::pt* out) {
 
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out) {
     PLK_TRY(msm_flush_reductions(ctx));
-    PLK_HIP(hipEventSynchronize(s.done));
-    msm_host_tail(s.marg_host, out);
+    PLK_HIP(hipEventSynchronize(ctx->slot[s.done_owner].done));
+    msm_host_tail(s.marg_host, s.plan_c, out);
     return PLK_OK;
 }
 
@@ -769,11 +965,13 @@ int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out) {
 static int32_t srs_alloc(plk_ctx* ctx, uint64_t shard_first, uint64_t shard_len, uint64_t total_len) {
     if (shard_first + shard_len > total_len || shard_len == 0 || shard_len + 3 >= (1ull << 27)) { ctx->err = "bad SRS shard"; return PLK_ERR_INVALID_ARG; }
     if (ctx->tables) { PLK_HIP(hipDeviceSynchronize()); PLK_HIP(hipFree(ctx->tables)); ctx->tables = nullptr; }
+    if (ctx->tables_short) { PLK_HIP(hipFree(ctx->tables_short)); ctx->tables_short = nullptr; }
+    ctx->short_len = 0; ctx->short_stride = 0;
     ctx->srs_total = total_len; ctx->shard_first = shard_first; ctx->shard_len = shard_len;
     ctx->cyc_world = 1; ctx->cyc_rank = 0; ctx->cyc_log_block = 0;
     ctx->has_gamma = shard_first == 0;
     ctx->table_stride = shard_len + 3;
-    PLK_HIP(hipMalloc(&ctx->tables, (size_t)MSM_WINDOWS * ctx->table_stride * 64));
+    PLK_HIP(hipMalloc(&ctx->tables, (size_t)MsmPlan<MSM_C>::WINDOWS * ctx->table_stride * 64));
     if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(ctx->tables + 16 * shard_len, 0, 3 * 64, ctx->stream));
     return PLK_OK;
 }
@@ -791,14 +989,42 @@ static int32_t srs_alloc_cyclic(plk_ctx* ctx, uint32_t rank, uint32_t world, uin
     if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(ctx->tables + 16 * ctx->shard_len, 0, 3 * 64, ctx->stream));
     return PLK_OK;
 }
+// MSMs of at most this many scalars (on this rank) take the 13-bit plan.  Chosen where the narrow plan stops paying: it adds a
+// quarter to the additions of the accumulation and takes seven eighths off the reduction of the buckets.  Measured: a proof of 2^16
+// gates (MSMs of 2^16 scalars) 4.02-4.04 ms against 4.14-4.2 ms with 16-bit windows throughout; one rank of eight at 2^20 gates
+// (MSMs of 2^17 scalars) 7.3 against 6.8 ms.  PLK_MSM_SHORT_MAX overrides it (0: every MSM on 16-bit windows).
+static uint64_t short_max_setting() {
+    const char* e = getenv("PLK_MSM_SHORT_MAX");
+    if (e && *e) return strtoull(e, nullptr, 0);
+    return (1ull << 16) + 4096;
+}
 static int32_t srs_build_tables(plk_ctx* ctx) {
     const uint64_t cnt = ctx->has_gamma ? ctx->shard_len + 3 : ctx->shard_len;   // a cyclic shard of a short SRS may hold no point at all
-    for (int j = 1; j < MSM_WINDOWS && cnt > 0; ++j) {
+    for (int j = 1; j < MsmPlan<MSM_C>::WINDOWS && cnt > 0; ++j) {
         const uint32_t* prev = ctx->tables + (size_t)(j - 1) * ctx->table_stride * 16;
         uint32_t* next = ctx->tables + (size_t)j * ctx->table_stride * 16;
-        hipLaunchKernelGGL(k_table_next, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, cnt);
+        hipLaunchKernelGGL(k_table_next, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, cnt, MSM_C);
     }
     PLK_HIP(hipGetLastError());
+    // Tables of the narrow plan over a prefix of this rank's points (every MSM of the prover starts at power 0, so a short MSM lies in
+    // the prefix) and the gamma powers: 20 windows x (prefix + 3) points, 170 MB at most.
+    ctx->short_max = short_max_setting();
+    if (ctx->short_max > 0 && ctx->shard_len > 0) {
+        ctx->short_len = std::min<uint64_t>(ctx->shard_len, ctx->short_max);
+        ctx->short_stride = ctx->short_len + 3;
+        constexpr int W = MsmPlan<MSM_C_SHORT>::WINDOWS;
+        PLK_HIP(hipMalloc(&ctx->tables_short, (size_t)W * ctx->short_stride * 64));
+        PLK_HIP(hipMemcpyAsync(ctx->tables_short, ctx->tables, ctx->short_len * 64, hipMemcpyDeviceToDevice, ctx->stream));
+        PLK_HIP(hipMemcpyAsync(ctx->tables_short + 16 * ctx->short_len, ctx->tables + 16 * ctx->shard_len, 3 * 64, hipMemcpyDeviceToDevice, ctx->stream));   // zeros on the ranks without gamma powers
+        const uint64_t scnt = ctx->has_gamma ? ctx->short_stride : ctx->short_len;
+        for (int j = 1; j < W; ++j) {
+            const uint32_t* prev = ctx->tables_short + (size_t)(j - 1) * ctx->short_stride * 16;
+            uint32_t* next = ctx->tables_short + (size_t)j * ctx->short_stride * 16;
+            hipLaunchKernelGGL(k_table_next, dim3((unsigned)((scnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, scnt, MSM_C_SHORT);
+            if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(next + 16 * ctx->short_len, 0, 3 * 64, ctx->stream));
+        }
+        PLK_HIP(hipGetLastError());
+    }
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     return slots_reserve(ctx);
 }

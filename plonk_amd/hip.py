@@ -27,7 +27,7 @@ EXPORTS = [
     "plk_scale_powers_dev", "plk_ntt_cross_dev", "plk_ntt_sharded_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
     "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_grand_product_dev_enqueue", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_dev_enqueue", "plk_quotient_dev_finish", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
-    "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_end",
+    "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_begin_batch", "plk_kzg_commit_end",
     "plk_kzg_open_begin", "plk_kzg_open_begin_batch", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_compute_detach", "plk_comm_get_unique_id", "plk_comm_init", "plk_comm_destroy", "plk_comm_all_gather_partials", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
 ]
@@ -402,6 +402,16 @@ class Context:
         self._ck(self.lib.plk_kzg_open_begin(self.h, _vp(d_coeffs), C.c_uint64(length), _ptr(_fr(blind, (12,))), _ptr(_fr(zeta, (4,))),
                                              _ptr(_fr(chal, (4,))), C.byref(t)))
         return t.value
+
+    def commit_begin_batch(self, d_coeffs, lengths, blinds):
+        """plk_kzg_commit_begin_batch -> list of tickets"""
+        count = len(d_coeffs)
+        ptrs = (C.c_void_p * count)(*[C.c_void_p(p if p else None) for p in d_coeffs])
+        lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+        b = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(count, 12)
+        t = np.full(count, -1, dtype=np.int32)
+        self._ck(self.lib.plk_kzg_commit_begin_batch(self.h, C.c_uint32(count), ptrs, _ptr(lens), _ptr(b), _ptr(t)))
+        return [int(x) for x in t]
 
     def open_begin_batch(self, d_coeffs, lengths, blinds, zeta, chal):
         """plk_kzg_open_begin_batch: d_coeffs / lengths per polynomial, blinds (count, 12) -> list of tickets"""

@@ -233,10 +233,24 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
             for (size_t r = 1; r < rest.size(); ++r) order[k++] = rest[r];
         }
         int32_t ticket[7];
-        for (int k = 0; k < 7; ++k) {
-            const int i = order[k];
-            if (in.host) check(ctx, plk_upload_enqueue(ctx, in.poly[i], in.host->poly[i], in.len[i] * 32));
-            check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
+        if (in.host) {
+            for (int k = 0; k < 7; ++k) {
+                const int i = order[k];
+                check(ctx, plk_upload_enqueue(ctx, in.poly[i], in.host->poly[i], in.len[i] * 32));
+                check(ctx, plk_kzg_commit_begin(ctx, in.poly[i], in.len[i], &blind[i][0].v[0], &ticket[i]));
+            }
+        } else {
+            // one call for the round: the library sees all seven lengths and places the long s_sigma's sort where it holds up nobody
+            const void* p7[7];
+            uint64_t l7[7], b7[7][12];
+            int32_t in_order[7];
+            for (int k = 0; k < 7; ++k) {
+                const int i = order[k];
+                p7[k] = in.poly[i]; l7[k] = in.len[i];
+                memcpy(b7[k], &blind[i][0].v[0], 96);
+            }
+            check(ctx, plk_kzg_commit_begin_batch(ctx, 7, p7, l7, &b7[0][0], in_order));
+            for (int k = 0; k < 7; ++k) ticket[order[k]] = in_order[k];
         }
         if (in.host) {   // needed from round 2 on: behind the polynomials
             check(ctx, plk_upload_enqueue(ctx, in.witness_flat, in.host->witness_flat, 3 * n * 32));

@@ -14,6 +14,18 @@ template <class F> static void op(int what, const uint32_t* a, const uint32_t* b
         case 5: { fe d = sub2<F>(x, y); norm(d); r = fe_zero(); r.v[0] = is_zero_mod<F>(d) ? 1 : 0; break; }
         case 6: { fe d = sub32<F>(x, y); norm(d); r = fe_zero(); r.v[0] = is_zero_mod<F>(d) ? 1 : 0; break; }
         case 8: { fe t = sub8<F>(x, y); fe n = sub4<F>(fe_zero(), y); r = mul2<F>(x, t, n, y); break; }   // x (x - y) - y y, operands as fat as xyzz_madd makes them
+        case 9: {   // Shoup product of a fat x (x + 8p + ..., not normalized) with the fixed operand y: y arrives as y * 2^261 mod p in b
+            fe fat = sub8<F>(x, fe_zero());          // x + 8p, limbs up to 2^29 + 2^30
+            fat = add(fat, fat);                      // 2x + 16p: limbs up to 2.5 * 2^30, bound 18
+            const shoup c = shoup_of<F>(reduce<F>(mul<F>(y, fe_const(F::R2))));
+            r = reduce3<F>(mul_shoup<F>(fat, c));     // 2 x y mod p
+            break;
+        }
+        case 10: {  // the same with the negated operand
+            const shoup c = shoup_neg<F>(shoup_of<F>(reduce<F>(mul<F>(y, fe_const(F::R2)))));
+            r = reduce3<F>(mul_shoup<F>(x, c));       // -x y mod p
+            break;
+        }
         default: r = x;
     }
     pack(reduce<F>(r), out);

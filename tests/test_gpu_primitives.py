@@ -313,6 +313,79 @@ def test_kzg_commit_open(ctx, orc, srs, length):
     assert np.array_equal(ev, want_ev)
 
 
+@pytest.mark.parametrize("short_max", ["0", "1000000"])
+def test_msm_edge_cases_on_both_window_plans(orc, monkeypatch, short_max):
+    """The library has two window plans: 16-bit windows (2^15 buckets) and, for MSMs of at most PLK_MSM_SHORT_MAX scalars, 13-bit
+    windows (2^12 buckets, 20 digits per scalar).  The setting is read when the SRS tables are built, so each plan can be forced
+    for a whole context: 0 puts every MSM on the wide plan, a large value puts every MSM of this test on the narrow one.  Both must
+    agree with the oracle on the scalars that exercise the recoding (0, 1, r - 1, digits 2^12, 2^12 + 1, 2^15, 2^15 + 1, all-ones
+    windows), on repeated bases (doubling and cancellation branches), on ragged lengths, and on hiding commitments / openings
+    begun singly and as batches."""
+    from plonk_amd.hip import Context
+    monkeypatch.setenv("PLK_MSM_SHORT_MAX", short_max)
+    c = Context(0)
+    n = 5000
+    tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
+    c.srs_generate(tau, gs, n + 1)
+    one = orc.fr_from_ints([1])[0]
+    g = orc.srs_powers(tau, one, 0, n + 1); gg = orc.srs_powers(tau, gs, 0, 3)
+    assert np.array_equal(c.srs_read(0, 0, n + 1), g) and np.array_equal(c.srs_read(1, 0, 3), gg)
+    r = pm.R_MOD
+    edge = [0, 1, 2, r - 1, r - 2, (1 << 12), (1 << 12) + 1, (1 << 12) - 1, (1 << 13) - 1, 1 << 13, (1 << 15), (1 << 15) + 1, (1 << 16) - 1, 1 << 16,
+            (1 << 253) + 5, int("1" * 254, 2) % r, sum(1 << (13 * j + 12) for j in range(19)), sum(1 << (16 * j + 15) for j in range(15)),
+            sum(((1 << 12) + 1) << (13 * j) for j in range(19)) % r, sum(((1 << 15) + 1) << (16 * j) for j in range(15)) % r]
+    sc = orc.fr_from_ints(edge)
+    for k in (len(edge), 1, 5):
+        for off in (0, 7, n - len(edge)):
+            got, inf = c.msm(sc[:k], base_offset=off)
+            want, winf = orc.msm(sc[:k], g[off:off + k])
+            assert inf == winf and np.array_equal(got, want), (k, off)
+    # the same base many times: sum of +-P with doublings and cancellations inside one bucket
+    for pattern in ([5] * 64, [7, r - 7] * 32, [1 << 12] * 33, [r - (1 << 15)] * 17 + [1 << 15] * 17):
+        scal = orc.fr_from_ints(pattern)
+        got, inf = c.msm(scal, base_offset=3)
+        want, winf = orc.msm(scal, g[3:3 + len(pattern)])
+        assert inf == winf and np.array_equal(got, want), pattern[:2]
+    rep = np.repeat(g[11:12], 40, axis=0)
+    c2 = Context(0)
+    c2.srs_load(rep, gg)
+    for pattern in ([3] * 40, [9, r - 9] * 20, list(range(1, 41))):
+        scal = orc.fr_from_ints(pattern)
+        got, inf = c2.msm(scal)
+        want, winf = orc.msm(scal, rep[:len(pattern)])
+        assert inf == winf and np.array_equal(got, want), pattern[:2]
+    c2.close()
+    for k in (0, 1, 2, 3, 17, 64, 1000, 4096, 4097, n):
+        s_ = rand_fr(orc, k, 6000 + k)
+        got, inf = c.msm(s_)
+        want, winf = orc.msm(s_, g[:k])
+        assert inf == winf and np.array_equal(got, want), k
+    # commitments and openings, single and batched, ragged lengths
+    zeta, chal = rand_fr(orc, 2, 4321)
+    chal = orc.fr_from_ints([orc.fr_to_ints(chal)[0] & ((1 << 128) - 1)])[0]
+    lengths = [0, 1, 2, 3, 100, 2049, n]
+    polys = [rand_fr(orc, k, 7000 + k) for k in lengths]
+    blinds = np.stack([rand_fr(orc, 3, 7100 + k) for k in lengths])
+    devs = [c.upload(p) for p in polys]
+    tickets = c.commit_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12))
+    c.submit()
+    for i in (6, 0, 3, 1, 5, 2, 4):
+        got, inf = c.commit_end(tickets[i])
+        want, winf = orc.kzg_commit(g, gg, polys[i], blinds[i])
+        assert inf == winf and np.array_equal(got, want), lengths[i]
+        single = c.kzg_commit(polys[i], blinds[i])
+        assert single[1] == winf and np.array_equal(single[0], want), lengths[i]
+    tickets = c.open_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12), zeta, chal)
+    for i in range(len(lengths)):
+        w, winf, rv, ev = c.open_end(tickets[i])
+        ow, oinf, orv = orc.kzg_open(g, gg, polys[i], blinds[i], zeta, chal)
+        assert winf == oinf and np.array_equal(w, ow) and np.array_equal(rv, orv), lengths[i]
+        assert np.array_equal(ev, orc.poly_eval(polys[i], zeta) if lengths[i] else np.zeros(4, dtype=np.uint64)), lengths[i]
+    for d in devs:
+        c.free(d)
+    c.close()
+
+
 def test_open_batch_matches_single_openings_and_the_oracle(orc):
     """plk_kzg_open_begin_batch (the nine openings of src/prover.rs:295-303 as one call): same points, random_v and evaluations as
     plk_kzg_open on each polynomial and as the oracle's long division + MSM, for ragged lengths that include the empty polynomial,

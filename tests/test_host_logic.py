@@ -58,6 +58,9 @@ def test_fp29_arithmetic(fp29, field):
         assert _call(fn, 7, a) == a                                   # unpack / pack round trip
         assert _call(fn, 5, a, b) == (1 if a == b else 0)             # exact zero test on lazily reduced values
         assert _call(fn, 5, a, a) == 1 and _call(fn, 6, a, a) == 1
+        assert _call(fn, 9, a, b) == 2 * a * b % p                    # fixed-operand (Shoup) product, lazily reduced x of bound 18
+        if b:
+            assert _call(fn, 10, a, b) == (-a * b) % p                # ... with the negated operand derived from the pair
     for x in vals[10:40] + [1, p - 1]:
         assert _call(fn, 4, x * (1 << 261) % p) == pow(x, -1, p) * (1 << 261) % p
 
