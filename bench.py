@@ -217,7 +217,8 @@ def main():
     # block-cyclic point ranges (blocks of 4096 powers dealt to the ranks in turn): every MSM of the proof, the n-coefficient ones
     # and the 4n-coefficient one alike, is split evenly; contiguous ranges of the 4n + 1 powers would leave the first ranks
     # with all of the n-coefficient polynomials
-    pk.generate_srs_cyclic(tau, gscal, total, rank, world, log_block=12)
+    log_block = synth.cyclic_log_block(log_n)
+    pk.generate_srs_cyclic(tau, gscal, total, rank, world, log_block=log_block)
     if world > 1:
         bufs = {}
 
@@ -394,7 +395,7 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "synthetic 2^%d-gate random arithmetic circuit, BN254, hiding KZG10, full proof (BASELINE.json configs[2])" % log_n,
                    "log_gates": log_n, "srs_points": total, "msm_pairs_per_proof": 20 * n + 45, "ntt_per_proof": 4,
-                   "parallelism": "1 GPU" if world == 1 else "MSM sharded over %d GPUs by block-cyclic point ranges (4096 points per block), partial sums exchanged by %s; other rounds replicated" % (world, collective)},
+                   "parallelism": "1 GPU" if world == 1 else "MSM sharded over %d GPUs by block-cyclic point ranges (%d points per block), partial sums exchanged by %s; other rounds replicated" % (world, 1 << log_block, collective)},
         "msm_gpts_per_s": round((20 * n + 45) / (ms_per_step * 1e-3) / 1e9, 4),
         "stage_ms": {k: round(float(v) / args.steps * 1e3, 3) for k, v in zip(["round1_commit", "grand_product", "quotient", "open", "assemble", "total"], stage)},
         "kernel_ms_per_proof": {k: round(v[0] / breakdown_steps, 3) for k, v in breakdown.items()},

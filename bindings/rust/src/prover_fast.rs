@@ -19,7 +19,6 @@
 //! life of the process, keyed by the address of the key's `powers` vector.
 //! NOT COMPILED in this repository (no Rust toolchain); the C++ host prover it calls is what the tests drive.
 use std::cell::RefCell;
-use std::collections::HashMap;
 use std::ffi::{c_void, CStr};
 
 use ark_bn254::{Bn254, Fr, G1Affine};
@@ -36,6 +35,7 @@ use crate::prover::{KZGCommitment, KZGOpeningProof, KZGProverKey, PlonkProof};
 extern "C" {
     fn plonk_host_last_error() -> *const std::os::raw::c_char;
     fn plonk_pk_create(device: i32, pk_out: *mut *mut c_void) -> i32;
+    fn plonk_pk_destroy(pk: *mut c_void) -> i32;
     fn plonk_pk_load(pk: *mut c_void, g_xy: *const u64, len: u64, gamma_g_xy: *const u64) -> i32;
     fn plonk_pk_set_opening_challenge(pk: *mut c_void, challenge: *const u64) -> i32;
     fn plonk_prove_host(pk: *mut c_void, polys: *const *const u64, lens: *const u64, witness_flat: *const u64, sigma: *const u64, log_n: u32,
@@ -51,17 +51,56 @@ fn check(rc: i32) {
     }
 }
 
+/// Identity of a key by CONTENT, not by address: an address is reused once a key has been dropped, and a stale device SRS behind a
+/// new key would give wrong proofs without any error.  Length plus the first, the middle and the last power (three distinct
+/// multiples of one generator: two different SRS do not share them) plus the first gamma power.
+#[derive(Clone, PartialEq, Eq, Hash)]
+struct KeyId {
+    len: usize,
+    probe: [[u64; 8]; 4],
+}
+fn key_id(pk: &KZGProverKey) -> KeyId {
+    let xy = |p: &G1Affine| -> [u64; 8] {
+        let mut o = [0u64; 8];
+        o[..4].copy_from_slice(&(p.x.0).0);
+        o[4..].copy_from_slice(&(p.y.0).0);
+        o
+    };
+    let n = pk.powers.len();
+    assert!(n > 0 && !pk.powers_of_gamma_g.is_empty());
+    KeyId { len: n, probe: [xy(&pk.powers[0]), xy(&pk.powers[n / 2]), xy(&pk.powers[n - 1]), xy(&pk.powers_of_gamma_g[0])] }
+}
+/// Device side of one key; released (SRS tables, scratch, streams) when the owning thread ends or the cache evicts it.
+struct GpuKey(*mut c_void);
+impl Drop for GpuKey {
+    fn drop(&mut self) {
+        unsafe { plonk_pk_destroy(self.0) };
+    }
+}
+const MAX_CACHED_KEYS: usize = 4; // a 2^22-point SRS holds about 10 GB of HBM with its tables and scratch
+
 thread_local! {
     // the reference is single threaded; a key's GPU side belongs to the thread that first used it
-    static KEYS: RefCell<HashMap<usize, *mut c_void>> = RefCell::new(HashMap::new());
+    static KEYS: RefCell<Vec<(KeyId, GpuKey)>> = RefCell::new(Vec::new());
 }
 
 /// GPU side of `pk`, created on first use: `powers` and `powers_of_gamma_g` of marlin_pc::CommitterKey go to HBM (PCS::trim's
-/// output, src/main.rs:183), the opening challenge of `test_sponge` is computed once.
+/// output, src/main.rs:183), the opening challenge of `test_sponge` is computed once.  Least recently used keys are dropped
+/// beyond MAX_CACHED_KEYS.
 fn gpu_key(pk: &KZGProverKey) -> *mut c_void {
-    let id = pk.powers.as_ptr() as usize;
+    let id = key_id(pk);
     KEYS.with(|keys| {
-        *keys.borrow_mut().entry(id).or_insert_with(|| {
+        let mut keys = keys.borrow_mut();
+        if let Some(pos) = keys.iter().position(|(k, _)| *k == id) {
+            let entry = keys.remove(pos);
+            let h = (entry.1).0;
+            keys.push(entry); // most recently used last
+            return h;
+        }
+        if keys.len() >= MAX_CACHED_KEYS {
+            keys.remove(0); // Drop releases its device memory
+        }
+        let h = {
             let mut h: *mut c_void = std::ptr::null_mut();
             check(unsafe { plonk_pk_create(0, &mut h) });
             assert!(pk.powers_of_gamma_g.len() >= 3, "hiding bound 1 needs three powers of gamma_g");
@@ -81,7 +120,9 @@ fn gpu_key(pk: &KZGProverKey) -> *mut c_void {
             let c: Fr = sponge.squeeze_field_elements_with_sizes(&[FieldElementSize::Truncated(128)])[0];
             check(unsafe { plonk_pk_set_opening_challenge(h, (c.0).0.as_ptr()) });
             h
-        })
+        };
+        keys.push((id, GpuKey(h)));
+        h
     })
 }
 

@@ -255,6 +255,15 @@ int32_t plk_kzg_cancel(plk_ctx* ctx);
 /* Like *_end but returns this shard's unnormalised partial (16 limbs) instead of the affine point. */
 int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t out_xyzz[16], uint64_t random_v[4], uint64_t eval[4]);
 
+/* Ends `count` tickets with one call.  out: 16 limbs per ticket, the affine point x || y in the first eight when affine != 0 (and
+ * is_inf[k]), the unnormalised partial sum (as plk_kzg_end_partial) otherwise; random_v / eval: 4 limbs per ticket, written for
+ * openings, may be NULL.  Same values as the single calls; the host-side ends of the MSMs (about 140 point additions and one
+ * inversion each) are shared among a few threads of the library, and results that have arrived are finished while the device still
+ * works on the others.  plk_g1_sum_partials_many is plk_g1_sum_partials for `count` points: xyzz = [world][count][16] limbs. */
+int32_t plk_kzg_end_many(plk_ctx* ctx, uint32_t count, const int32_t* tickets, int32_t affine, uint64_t* out, int32_t* is_inf, uint64_t* random_v,
+                         uint64_t* eval);
+int32_t plk_g1_sum_partials_many(const uint64_t* xyzz, uint64_t world, uint64_t count, uint64_t* out_xy, int32_t* out_is_inf);
+
 /* ---- multi-GPU exchange inside the library (no counterpart in the reference, which is a single process).  One process per GPU;
  * every rank holds a shard of the SRS (plk_srs_*_cyclic), runs the same prover, and every commitment or opening is the sum of the
  * ranks' partial sums (plk_kzg_end_partial).  Rank 0 calls plk_comm_get_unique_id and hands the 128 bytes to the other ranks by any

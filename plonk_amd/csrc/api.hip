@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include "common.cuh"
@@ -97,13 +98,13 @@ int32_t order_streams(plk_ctx* ctx, hipStream_t first, hipStream_t then) {
     return PLK_OK;
 }
 // The front work of every second job runs on the reduction stream and reads the job's polynomial there, while the calls that may
-// overwrite that polynomial afterwards (transforms in place, copies, uploads, pointwise kernels) run on the front stream.  The end of
-// the last such read is marked here, and the next compute call on the front stream waits for the mark: the ordering costs nothing
-// until somebody needs it (making the front stream wait at once would hold up the sort of the job after next).
-int32_t lane_read_mark(plk_ctx* ctx, hipStream_t lane) {
+// overwrite that polynomial afterwards (transforms in place, copies, uploads, pointwise kernels) run on the front stream.  The job's
+// own `sorted` event (recorded behind its division and sort) serves as the mark of its last read, and the next compute call on the
+// front stream waits for it: the ordering costs nothing until somebody needs it (making the front stream wait at once would hold up
+// the sort of the job after next; an event of its own between the sort's kernels cost 0.08 ms per proof of 2^20 gates).
+int32_t lane_read_mark(plk_ctx* ctx, hipStream_t lane, hipEvent_t recorded) {
     if (ctx->detached || lane != ctx->st_red) return PLK_OK;
-    if (!ctx->lane_read) PLK_HIP(hipEventCreateWithFlags(&ctx->lane_read, hipEventDisableTiming));
-    PLK_HIP(hipEventRecord(ctx->lane_read, lane));
+    ctx->lane_read = recorded;
     ctx->lane_read_pending = true;
     return PLK_OK;
 }
@@ -315,7 +316,6 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     if (ctx->prof_base) hipEventDestroy(ctx->prof_base);
     for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
     for (hipEvent_t e : ctx->order_ev) if (e) hipEventDestroy(e);
-    if (ctx->lane_read) hipEventDestroy(ctx->lane_read);
     hipFree(ctx->batch_dev); hipHostFree(ctx->batch_host);
     if (ctx->comm) plk_comm_destroy(ctx);
     for (auto& s : ctx->slot) slot_destroy(s);
@@ -842,7 +842,6 @@ static int32_t open_begin_on(plk_ctx* ctx, int si, hipStream_t lane, const void*
     const bool cyclic = ctx->cyc_world > 1;
     PLK_TRY(division_enqueue(ctx, lane, (const uint32_t*)coeffs_dev, len, zeta, challenge, s.scal_dev, s.res_dev, s.chain_dev,
                              cyclic ? 0 : ctx->shard_first, cyclic ? len : ctx->shard_len));
-    PLK_TRY(lane_read_mark(ctx, lane));            // the division is the last reader of the caller's polynomial
     PLK_HIP(hipMemcpyAsync(s.res_host, s.res_dev, 32, hipMemcpyDeviceToHost, lane));
     s.eval_host = s.res_host; s.in_batch = false;
     hiding_part(blind, zeta, challenge, s.host_rv, s.blind_host);
@@ -1001,6 +1000,149 @@ extern "C" int32_t plk_kzg_end_partial(plk_ctx* ctx, int32_t ticket, uint64_t ou
     }
     return PLK_OK;
 }
+// ---- ending several tickets at once ------------------------------------------------------------------------------------
+// Every MSM ends on the host with about 140 point additions and, for an affine result, one inversion: 60-100 microseconds of one
+// core.  A round ends with several results arriving together (the short MSMs of a small proof share their reduction launch; a
+// rank of a sharded proof has nine short MSMs), and their tails, done one after the other, were a tenth of such a proof.  A few
+// helper threads share them: the tail is cut into five independent pieces per MSM (the sum of all buckets and one weighted sum per
+// bit-field), then one combination and inversion per MSM.
+namespace {
+struct WorkPool {
+    static constexpr int HELPERS = 3;
+    std::vector<std::thread> helpers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    int next = 0, total = 0, running = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+    void helper() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lock(m);
+            cv_work.wait(lock, [&] { return stop || (generation != seen && next < total); });
+            if (stop) return;
+            seen = generation;
+            ++running;
+            while (next < total) {
+                const int i = next++;
+                const std::function<void(int)>* f = job;
+                lock.unlock();
+                (*f)(i);
+                lock.lock();
+            }
+            if (--running == 0) cv_done.notify_all();
+        }
+    }
+    // f(0) .. f(n - 1) on the helpers and the calling thread; returns when all have run
+    void run(int n, const std::function<void(int)>& f) {
+        if (n <= 1 || helpers.empty()) { for (int i = 0; i < n; ++i) f(i); return; }
+        {
+            std::lock_guard<std::mutex> lock(m);
+            job = &f; next = 0; total = n; ++generation;
+        }
+        cv_work.notify_all();
+        std::unique_lock<std::mutex> lock(m);
+        ++running;
+        while (next < total) {
+            const int i = next++;
+            lock.unlock();
+            f(i);
+            lock.lock();
+        }
+        --running;
+        cv_done.wait(lock, [&] { return running == 0; });
+        total = 0; job = nullptr;
+    }
+    WorkPool() { for (int i = 0; i < HELPERS; ++i) helpers.emplace_back([this] { helper(); }); }
+    ~WorkPool() {
+        { std::lock_guard<std::mutex> lock(m); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : helpers) t.join();
+    }
+};
+WorkPool& work_pool() { static WorkPool pool; return pool; }
+std::mutex g_pool_use;   // one caller at a time (contexts of different host threads share the pool)
+}  // namespace
+
+// Ends `count` tickets: out receives 16 limbs per ticket, the affine point x || y in the first eight when affine != 0 (is_inf[k]
+// set), the unnormalised partial sum X, Y, ZZ, ZZZ otherwise.  random_v / eval (4 limbs per ticket) are filled for openings and may
+// be null.  Tickets whose results have arrived are finished while the device still works on the others.
+extern "C" int32_t plk_kzg_end_many(plk_ctx* ctx, uint32_t count, const int32_t* tickets, int32_t affine, uint64_t* out, int32_t* is_inf, uint64_t* random_v,
+                                    uint64_t* eval) {
+    if (!ctx || !count || !tickets || !out || (affine && !is_inf) || count > (uint32_t)MSM_SLOTS) return PLK_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (tickets[k] < 0 || tickets[k] >= MSM_SLOTS || !ctx->slot[tickets[k]].busy) { ctx->err = "bad ticket"; return PLK_ERR_INVALID_ARG; }
+        for (uint32_t j = 0; j < k; ++j) if (tickets[j] == tickets[k]) { ctx->err = "ticket listed twice"; return PLK_ERR_INVALID_ARG; }
+    }
+    PLK_HIP(hipSetDevice(ctx->device));
+    PLK_TRY(msm_flush_reductions(ctx));
+    std::vector<uint32_t> pending(count);
+    for (uint32_t k = 0; k < count; ++k) pending[k] = k;
+    int32_t rc = PLK_OK;
+    while (!pending.empty() && rc == PLK_OK) {
+        // everything that has arrived; when nothing has, the ticket listed first is waited for
+        std::vector<uint32_t> ready, rest;
+        for (uint32_t k : pending) {
+            const MsmSlot& s = ctx->slot[tickets[k]];
+            const hipError_t e = hipEventQuery(ctx->slot[s.done_owner].done);
+            if (e == hipSuccess) ready.push_back(k);
+            else if (e == hipErrorNotReady) rest.push_back(k);
+            else { ctx->err = hipGetErrorString(e); rc = PLK_ERR_HIP; break; }
+        }
+        if (rc != PLK_OK) break;
+        if (ready.empty()) {
+            const MsmSlot& s = ctx->slot[tickets[pending[0]]];
+            if (hipEventSynchronize(ctx->slot[s.done_owner].done) != hipSuccess) { ctx->err = "waiting for a result failed"; rc = PLK_ERR_HIP; break; }
+            continue;
+        }
+        const int n = (int)ready.size();
+        std::vector<host::pt> pieces((size_t)n * MSM_TAIL_PIECES);
+        const std::function<void(int)> piece = [&](int i) {
+            const MsmSlot& s = ctx->slot[tickets[ready[i / MSM_TAIL_PIECES]]];
+            msm_tail_piece(s.marg_host, s.plan_c, i % MSM_TAIL_PIECES, &pieces[i]);
+        };
+        const std::function<void(int)> finish = [&](int i) {
+            const uint32_t k = ready[i];
+            const MsmSlot& s = ctx->slot[tickets[k]];
+            host::pt r;
+            msm_tail_combine(&pieces[(size_t)i * MSM_TAIL_PIECES], s.plan_c, &r);
+            if (affine) { host::pt_to_affine(r, out + 16 * k, &is_inf[k]); memset(out + 16 * k + 8, 0, 64); }
+            else host::pt_store(r, out + 16 * k);
+        };
+        {
+            std::lock_guard<std::mutex> lock(g_pool_use);
+            work_pool().run(n * MSM_TAIL_PIECES, piece);
+            work_pool().run(n, finish);
+        }
+        for (uint32_t k : ready) {
+            MsmSlot& s = ctx->slot[tickets[k]];
+            if (s.kind == 2) {
+                if (random_v) memcpy(random_v + 4 * k, s.host_rv, 32);
+                if (eval) memcpy(eval + 4 * k, s.eval_host, 32);
+            }
+            slot_release(ctx, s);
+        }
+        pending.swap(rest);
+    }
+    if (rc != PLK_OK) for (uint32_t k : pending) slot_release(ctx, ctx->slot[tickets[k]]);
+    prof_collect(ctx, false);
+    return rc;
+}
+// plk_g1_sum_partials for `count` points at once: xyzz holds [world][count][16] limbs (what an all-gather of the ranks' partial sums
+// returns), out_xy [count][8], out_is_inf [count].
+extern "C" int32_t plk_g1_sum_partials_many(const uint64_t* xyzz, uint64_t world, uint64_t count, uint64_t* out_xy, int32_t* out_is_inf) {
+    if (!xyzz || !out_xy || !out_is_inf || !world) return PLK_ERR_INVALID_ARG;
+    const std::function<void(int)> one = [&](int i) {
+        host::pt acc = host::pt_inf();
+        for (uint64_t r = 0; r < world; ++r) acc = host::pt_add(acc, host::pt_load(xyzz + (r * count + (uint64_t)i) * 16));
+        host::pt_to_affine(acc, out_xy + 8 * (uint64_t)i, &out_is_inf[i]);
+    };
+    std::lock_guard<std::mutex> lock(g_pool_use);
+    work_pool().run((int)count, one);
+    return PLK_OK;
+}
+
 extern "C" int32_t plk_kzg_open_dev(plk_ctx* ctx, const void* coeffs_dev, uint64_t len, const uint64_t* blind, const uint64_t zeta[4],
                                     const uint64_t challenge[4], uint64_t w_xy[8], int32_t* w_is_inf, uint64_t random_v[4], uint64_t eval[4]) {
     int32_t t;

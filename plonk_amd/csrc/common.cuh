@@ -112,7 +112,8 @@ struct plk_ctx {
     hipEvent_t order_ev[ORDER_EVENTS] = {};
     unsigned order_turn = 0;
     // A *_begin whose front work went to the second front stream (st_red) reads its polynomial there.  lane_read marks the end of
-    // the last such read; compute work on the first front stream that may overwrite the polynomial waits for it (compute_guard).
+    // the last such read (the `sorted` event of that job's slot, not owned); compute work on the first front stream that may overwrite
+    // the polynomial waits for it (compute_guard).
     hipEvent_t lane_read = nullptr;
     bool lane_read_pending = false;
     int batch_open = 0;                // tickets of the last plk_kzg_open_begin_batch that have not ended yet
@@ -199,7 +200,7 @@ int32_t ensure_scratch(plk_ctx* ctx, uint64_t bytes);
 // everything enqueued on `first` so far is ordered before whatever is enqueued on `then` from now on
 int32_t order_streams(plk_ctx* ctx, hipStream_t first, hipStream_t then);
 // records the end of a polynomial read on the second front stream / orders the compute stream behind the last such read
-int32_t lane_read_mark(plk_ctx* ctx, hipStream_t lane);
+int32_t lane_read_mark(plk_ctx* ctx, hipStream_t lane, hipEvent_t recorded);
 int32_t compute_guard(plk_ctx* ctx);
 
 // Issue priority of the short kernels that run beside the accumulation kernel.

@@ -27,7 +27,11 @@ struct MsmJob {
 };
 int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset);   // MSM_C or MSM_C_SHORT
 int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStream_t lane, int idle_hint, int plan_c);
-int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);   // enqueues the pending reductions first
+int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);
+// the host tail of an MSM in independent pieces (for several host threads) and their combination
+constexpr int MSM_TAIL_PIECES = 5;
+void msm_tail_piece(const uint32_t* marg, int plan_c, int piece, host::pt* out);
+void msm_tail_combine(const host::pt* pieces, int plan_c, host::pt* out);   // enqueues the pending reductions first
 int32_t msm_flush_reductions(plk_ctx* ctx);
 void slot_destroy(MsmSlot& s);
 

@@ -792,8 +792,8 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
     if (narrow) launch_sort<MSM_C_SHORT>(st, sb, max_blocks, n, fast);
     else launch_sort<MSM_C>(st, sb, max_blocks, n, fast);
     prof_end(ctx, st);
-    PLK_TRY(lane_read_mark(ctx, st));          // the digit kernel is the last reader of the callers' scalars; the mark covers the whole sort
     PLK_HIP(hipEventRecord(leader.sorted, st));
+    PLK_TRY(lane_read_mark(ctx, st, leader.sorted));   // behind the last reader of the callers' scalars (and of the division in front of the sort)
     // The accumulation goes to the stream with less work queued (entries of the jobs enqueued since the device was last idle): the kernel
     // behind a long one would otherwise wait for it to drain completely while the other stream has nothing left to run.
     if (idle) ctx->acc_load[0] = ctx->acc_load[1] = 0;
@@ -935,23 +935,43 @@ int32_t msm_flush_reductions(plk_ctx* ctx) {
 }
 
 // Host tail: sum_k k*B_k from the marginal sums.  weight of bucket index idx is idx + 1.
-void msm_host_tail(const uint32_t* marg, int plan_c, host::pt* out) {
+// In pieces, so that several host threads can share one tail: piece 0 = the sum of all buckets (the "+1": every bucket has exactly
+// one value in field 0), piece 1 + d = sum_v v M(d, v) of field d by running sums; msm_tail_combine puts them together.
+constexpr int TAIL_PIECES = 1 + 4;
+static int plan_fields(int plan_c) { return plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::FIELDS : MsmPlan<MSM_C>::FIELDS; }
+static int plan_last_bits(int plan_c) { return plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::LAST_BITS : MsmPlan<MSM_C>::LAST_BITS; }
+void msm_tail_piece(const uint32_t* marg, int plan_c, int piece, host::pt* out) {
     using namespace host;
     const uint64_t* m = reinterpret_cast<const uint64_t*>(marg);
     auto M = [&](int o) { return pt_load(m + 16 * o); };
-    const int fields = plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::FIELDS : MsmPlan<MSM_C>::FIELDS;
-    const int last_bits = plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::LAST_BITS : MsmPlan<MSM_C>::LAST_BITS;
-    pt total = pt_inf();
-    for (int v = 0; v < 16; ++v) total = pt_add(total, M(v));          // sum of all buckets (the "+1"): every bucket has exactly one value in field 0
+    const int fields = plan_fields(plan_c);
+    if (piece == 0) {
+        pt total = pt_inf();
+        for (int v = 0; v < 16; ++v) total = pt_add(total, M(v));
+        *out = total;
+        return;
+    }
+    const int d = piece - 1;
+    if (d >= fields) { *out = pt_inf(); return; }
+    const int nv = d < fields - 1 ? 16 : (1 << plan_last_bits(plan_c)), base = 16 * d;
+    pt run = pt_inf(), s = pt_inf();
+    for (int v = nv - 1; v >= 1; --v) { run = pt_add(run, M(base + v)); s = pt_add(s, run); }
+    *out = s;
+}
+void msm_tail_combine(const host::pt* pieces, int plan_c, host::pt* out) {
+    using namespace host;
+    const int fields = plan_fields(plan_c);
     pt acc = pt_inf();
     for (int d = fields - 1; d >= 0; --d) {
-        const int nv = d < fields - 1 ? 16 : (1 << last_bits), base = 16 * d;
-        pt run = pt_inf(), s = pt_inf();
-        for (int v = nv - 1; v >= 1; --v) { run = pt_add(run, M(base + v)); s = pt_add(s, run); }
         if (d < fields - 1) for (int k = 0; k < 4; ++k) acc = pt_dbl(acc);    // the field above sits 4 bits higher
-        acc = pt_add(acc, s);
+        acc = pt_add(acc, pieces[1 + d]);
     }
-    *out = pt_add(acc, total);
+    *out = pt_add(acc, pieces[0]);
+}
+void msm_host_tail(const uint32_t* marg, int plan_c, host::pt* out) {
+    host::pt pieces[TAIL_PIECES];
+    for (int i = 0; i < TAIL_PIECES; ++i) msm_tail_piece(marg, plan_c, i, &pieces[i]);
+    msm_tail_combine(pieces, plan_c, out);
 }
 
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out) {

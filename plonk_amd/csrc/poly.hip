@@ -210,10 +210,13 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(DivBatch db, uint32_t
     const uint64_t len = db.len[mb];
     const uint32_t cyc_world = db.cyc_world, cyc_rank = db.cyc_rank, cyc_log_block = db.cyc_log_block;
     const uint32_t t = threadIdx.x, blk = db.first_block[mb] + blockIdx.x;
+    // A workgroup writes the quotient coefficients k in [blk BLOCK, (blk + 1) BLOCK): q_k = scale h_(k+1), so the last one is the
+    // block's carry (h at the first coefficient of the next block) and the first coefficient's own h belongs to the block before.
+    // Aligned like this, the division blocks coincide with the blocks of a block-cyclic SRS shard of the same or a larger size.
     if (cyc_world > 1) {
         // block-cyclic shard: q_out[k] is only used for the SRS points k this rank holds (block k >> log_block congruent to rank);
-        // a workgroup whose coefficients (k = i - 1) touch none of them has nothing to write
-        const uint64_t k_lo = blk == 0 ? 0 : (uint64_t)blk * BLOCK - 1, k_hi = (uint64_t)blk * BLOCK + BLOCK - 2;
+        // a workgroup whose coefficients touch none of them has nothing to write
+        const uint64_t k_lo = (uint64_t)blk * BLOCK, k_hi = (uint64_t)blk * BLOCK + BLOCK - 1;
         const uint64_t b_lo = k_lo >> cyc_log_block, b_hi = k_hi >> cyc_log_block;
         bool need = b_hi - b_lo + 1 >= cyc_world;
         for (uint64_t b = b_lo; !need && b <= b_hi; ++b) need = b % cyc_world == cyc_rank;
@@ -230,13 +233,14 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(DivBatch db, uint32_t
 #pragma unroll
     for (int i = 0; i < 9; ++i) heads[t * 9 + i] = head.v[i];
     __syncthreads();
+    const fe sc = to_rp(fe_of(db.scale));
+    if (t == DIV_THREADS - 1 && (uint64_t)(blk + 1) * BLOCK < len) st_fe<FrP>(q_out + 8 * ((uint64_t)(blk + 1) * BLOCK - 1), mul<FrP>(cin, sc));
     if (lo >= len) return;
     fe h = cin;                                                         // h just above this thread's chunk
     if (t + 1 < DIV_THREADS) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) h.v[i] = heads[(t + 1) * 9 + i];
     }
-    const fe sc = to_rp(fe_of(db.scale));
 #pragma unroll 1
     for (int q = (1 << LOG_L) / 4 - 1; q >= 0; --q) {
         fe v[4];
@@ -246,7 +250,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(DivBatch db, uint32_t
             const uint64_t i = lo + 4 * q + k;
             if (i >= len) continue;
             h = add(v[k], mul<FrP>(h, z));      // bound 3, limbs < 2^30
-            if (i >= 1) st_fe<FrP>(q_out + 8 * (i - 1), mul<FrP>(h, sc));
+            if (i > (uint64_t)blk * BLOCK) st_fe<FrP>(q_out + 8 * (i - 1), mul<FrP>(h, sc));   // the block's first h belongs to the block before
         }
     }
 }
@@ -279,10 +283,10 @@ int32_t division_enqueue_batch(plk_ctx* ctx, hipStream_t st, uint32_t count, con
             db.log_block[n] = 8 + (uint32_t)div_log_l(j.len);
             db.first_block[n] = 0; db.apply_blocks[n] = 0;
             if (j.q_out && j.len > 1 && j.q_count > 0) {
-                // q_out[k] comes from coefficient k + 1: only the blocks that hold coefficients q_first + 1 .. q_first + q_count are walked
+                // block b writes q_out[k] for k in [b block, (b + 1) block): only the blocks that hold k = q_first .. q_first + q_count - 1 are walked
                 const uint64_t hi = std::min<uint64_t>(j.q_first + j.q_count, j.len - 1);
                 if (j.q_first < hi) {
-                    const uint32_t b0 = (uint32_t)((j.q_first + 1) / block), b1 = (uint32_t)(hi / block);
+                    const uint32_t b0 = (uint32_t)(j.q_first / block), b1 = (uint32_t)((hi - 1) / block);
                     db.first_block[n] = b0; db.apply_blocks[n] = b1 - b0 + 1;
                 }
             }

@@ -28,7 +28,7 @@ EXPORTS = [
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
     "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_grand_product_dev_enqueue", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_dev_enqueue", "plk_quotient_dev_finish", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
     "plk_kzg_commit", "plk_kzg_commit_dev", "plk_kzg_open", "plk_kzg_open_dev", "plk_kzg_commit_begin", "plk_kzg_commit_begin_batch", "plk_kzg_commit_end",
-    "plk_kzg_open_begin", "plk_kzg_open_begin_batch", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_compute_detach", "plk_comm_get_unique_id", "plk_comm_init", "plk_comm_destroy", "plk_comm_all_gather_partials", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
+    "plk_kzg_open_begin", "plk_kzg_open_begin_batch", "plk_kzg_open_end", "plk_kzg_end_partial", "plk_kzg_end_many", "plk_g1_sum_partials_many", "plk_kzg_submit", "plk_kzg_cancel", "plk_kzg_ready", "plk_compute_detach", "plk_comm_get_unique_id", "plk_comm_init", "plk_comm_destroy", "plk_comm_all_gather_partials", "plk_field_op", "plk_profile_enable", "plk_profile_reset",
     "plk_profile_get", "plk_profile_get_busy",
 ]
 
@@ -428,6 +428,23 @@ class Context:
         rv = np.empty(4, dtype=np.uint64); ev = np.empty(4, dtype=np.uint64)
         self._ck(self.lib.plk_kzg_open_end(self.h, C.c_int32(ticket), _ptr(w), C.byref(inf), _ptr(rv), _ptr(ev)))
         return w, inf.value, rv, ev
+
+    def end_many(self, tickets, affine=True):
+        """plk_kzg_end_many -> (points (count, 16), is_inf (count,), random_v (count, 4), eval (count, 4))"""
+        t = np.ascontiguousarray(tickets, dtype=np.int32)
+        n = len(t)
+        out = np.zeros((n, 16), dtype=np.uint64); inf = np.zeros(n, dtype=np.int32)
+        rv = np.zeros((n, 4), dtype=np.uint64); ev = np.zeros((n, 4), dtype=np.uint64)
+        self._ck(self.lib.plk_kzg_end_many(self.h, C.c_uint32(n), _ptr(t), C.c_int32(int(affine)), _ptr(out), _ptr(inf), _ptr(rv), _ptr(ev)))
+        return out, inf, rv, ev
+
+    def sum_partials_many(self, parts):
+        """parts: (world, count, 16) -> (xy (count, 8), is_inf (count,))"""
+        p = np.ascontiguousarray(parts, dtype=np.uint64)
+        world, count = p.shape[0], p.shape[1]
+        out = np.zeros((count, 8), dtype=np.uint64); inf = np.zeros(count, dtype=np.int32)
+        self._ck(self.lib.plk_g1_sum_partials_many(_ptr(p), C.c_uint64(world), C.c_uint64(count), _ptr(out), _ptr(inf)))
+        return out, inf
 
     def end_partial(self, ticket):
         out = np.empty(16, dtype=np.uint64); rv = np.zeros(4, dtype=np.uint64); ev = np.zeros(4, dtype=np.uint64)

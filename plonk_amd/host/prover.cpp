@@ -127,39 +127,24 @@ namespace {
 // is ready the one begun earliest is waited for.
 void finish_points(const KZGProverKey& pk, const int32_t* tickets, int count, bool is_open, G1Affine* out, Fr* random_v, Fr* eval, const int* order = nullptr) {
     plk_ctx* ctx = pk.ctx();
-    std::vector<int> pending(count);
-    for (int k = 0; k < count; ++k) pending[k] = order ? order[k] : k;
-    auto take_next = [&]() {
-        size_t pick = 0;
-        for (size_t k = 0; k < pending.size() && pending.size() > 1; ++k) {
-            int32_t ready = 0;
-            check(ctx, plk_kzg_ready(ctx, tickets[pending[k]], &ready));
-            if (ready) { pick = k; break; }
-        }
-        const int i = pending[pick];
-        pending.erase(pending.begin() + pick);
-        return i;
-    };
-    if (pk.world_size <= 1) {
-        while (!pending.empty()) {
-            const int i = take_next();
-            if (is_open) check(ctx, plk_kzg_open_end(ctx, tickets[i], out[i].xy, &out[i].infinity, random_v[i].v, eval[i].v));
-            else check(ctx, plk_kzg_commit_end(ctx, tickets[i], out[i].xy, &out[i].infinity));
-        }
+    // the tickets in the sequence in which they were begun: when nothing has arrived yet, the library waits for the first one listed
+    std::vector<int32_t> t(count);
+    std::vector<int> who(count);
+    for (int k = 0; k < count; ++k) { who[k] = order ? order[k] : k; t[k] = tickets[who[k]]; }
+    std::vector<uint64_t> pts((size_t)16 * count), rv((size_t)4 * count), ev((size_t)4 * count);
+    std::vector<int32_t> inf(count);
+    const bool sharded = pk.world_size > 1;
+    check(ctx, plk_kzg_end_many(ctx, (uint32_t)count, t.data(), sharded ? 0 : 1, pts.data(), inf.data(), rv.data(), ev.data()));
+    if (is_open)
+        for (int k = 0; k < count; ++k) { memcpy(random_v[who[k]].v, &rv[(size_t)4 * k], 32); memcpy(eval[who[k]].v, &ev[(size_t)4 * k], 32); }
+    if (!sharded) {
+        for (int k = 0; k < count; ++k) { memcpy(out[who[k]].xy, &pts[(size_t)16 * k], 64); out[who[k]].infinity = inf[k]; }
         return;
     }
-    std::vector<uint64_t> mine((size_t)16 * count), all((size_t)16 * count * pk.world_size), one((size_t)16 * pk.world_size);
-    while (!pending.empty()) {
-        const int i = take_next();
-        Fr rv{}, ev{};
-        check(ctx, plk_kzg_end_partial(ctx, tickets[i], &mine[(size_t)16 * i], rv.v, ev.v));
-        if (is_open) { random_v[i] = rv; eval[i] = ev; }
-    }
-    pk.gather(mine.data(), (uint64_t)count, all.data());
-    for (int i = 0; i < count; ++i) {
-        for (uint32_t r = 0; r < pk.world_size; ++r) memcpy(&one[(size_t)16 * r], &all[((size_t)r * count + i) * 16], 128);
-        check(ctx, plk_g1_sum_partials(one.data(), pk.world_size, out[i].xy, &out[i].infinity));
-    }
+    std::vector<uint64_t> all((size_t)16 * count * pk.world_size), xy((size_t)8 * count);
+    pk.gather(pts.data(), (uint64_t)count, all.data());
+    check(ctx, plk_g1_sum_partials_many(all.data(), pk.world_size, (uint64_t)count, xy.data(), inf.data()));
+    for (int k = 0; k < count; ++k) { memcpy(out[who[k]].xy, &xy[(size_t)8 * k], 64); out[who[k]].infinity = inf[k]; }
 }
 // Order in which the independent MSMs of one round are enqueued (results do not depend on it).  One ordinary-sized MSM leads so
 // that the accumulation stream starts after a short sort; the MSMs of a handful of terms follow at once, so that their
@@ -304,14 +289,22 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     check(ctx, plk_quotient_dev_enqueue(ctx, in.poly[0], in.poly[1], in.poly[2], in.work[0], in.work[1], in.work[3], in.sigma, log_n, beta.v, gamma.v, in.work[4]));
     // the commitments below are begun "detached": their sorts stay on the stream that carries z's coefficients
     for (auto& r : blind[7]) r = rng();
-    int32_t z_ticket;
-    check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
     // The quotient of this constraint system has degree < n before the division by Z_H, so it is either the zero polynomial or
     // the prover fails (:487).  Its commitment (three blinding terms, drawn here in the reference's rng order) is therefore
     // started now, beside z's, instead of after the divisibility check; a non-zero t would simply be committed again below.
     for (auto& r : blind[8]) r = rng();
-    int32_t t_ticket = -1;
-    check(ctx, plk_kzg_commit_begin(ctx, in.work[4], 0, &blind[8][0].v[0], &t_ticket));
+    int32_t z_ticket, t_ticket = -1;
+    {
+        // both in one call: when z is short enough for the narrow window plan the two share their launches
+        const void* p2[2] = {z_coeffs, in.work[4]};
+        const uint64_t l2[2] = {n, 0};
+        uint64_t b2[2][12];
+        int32_t t2[2];
+        memcpy(b2[0], &blind[7][0].v[0], 96);
+        memcpy(b2[1], &blind[8][0].v[0], 96);
+        check(ctx, plk_kzg_commit_begin_batch(ctx, 2, p2, l2, &b2[0][0], t2));
+        z_ticket = t2[0]; t_ticket = t2[1];
+    }
     lap(1);
 
     // ---- round 3: quotient t :224-259, on the detached compute stream.  The reductions of z and t (plk_kzg_submit) share that

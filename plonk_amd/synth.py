@@ -124,3 +124,10 @@ def trim(arr: np.ndarray) -> np.ndarray:
 def seeded_scalars(count: int, seed: int) -> np.ndarray:
     rng = SplitMix64(seed)
     return to_mont([rng.next_fr() for _ in range(count)])
+
+
+def cyclic_log_block(log_gates: int) -> int:
+    """Block size (as a power of two) of the block-cyclic SRS shards for a proof of 2^log_gates gates: a multiple of the block in which
+    the opening divisions walk their polynomials (2048 coefficients below 2^21 coefficients, 8192 from there on), so that a rank's
+    share of the quotient coefficients lies in whole division blocks and the division writes out nothing that another rank uses."""
+    return 13 if log_gates >= 21 else 12

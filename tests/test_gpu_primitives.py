@@ -381,6 +381,20 @@ def test_msm_edge_cases_on_both_window_plans(orc, monkeypatch, short_max):
         ow, oinf, orv = orc.kzg_open(g, gg, polys[i], blinds[i], zeta, chal)
         assert winf == oinf and np.array_equal(w, ow) and np.array_equal(rv, orv), lengths[i]
         assert np.array_equal(ev, orc.poly_eval(polys[i], zeta) if lengths[i] else np.zeros(4, dtype=np.uint64)), lengths[i]
+    # all tickets of a round ended with one call (plk_kzg_end_many: the host-side ends of the MSMs run on several threads), as affine
+    # points and as the partial sums a sharded prover exchanges
+    tickets = c.commit_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12))
+    pts, inf, _, _ = c.end_many(tickets[::-1])
+    for j, i in enumerate(reversed(range(len(lengths)))):
+        want, winf = orc.kzg_commit(g, gg, polys[i], blinds[i])
+        assert inf[j] == winf and np.array_equal(pts[j, :8], want), lengths[i]
+    tickets = c.open_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12), zeta, chal)
+    parts, _, rvs, evs = c.end_many(tickets, affine=False)
+    xy, inf = c.sum_partials_many(parts.reshape(1, len(lengths), 16))
+    for i in range(len(lengths)):
+        ow, oinf, orv = orc.kzg_open(g, gg, polys[i], blinds[i], zeta, chal)
+        assert inf[i] == oinf and np.array_equal(xy[i], ow) and np.array_equal(rvs[i], orv), lengths[i]
+        assert np.array_equal(evs[i], orc.poly_eval(polys[i], zeta) if lengths[i] else np.zeros(4, dtype=np.uint64)), lengths[i]
     for d in devs:
         c.free(d)
     c.close()

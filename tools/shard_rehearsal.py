@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--log-gates", type=int, default=20)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--log-block", type=int, default=0, help="points per block of the cyclic shards, as a power of two (0: what bench.py uses at this size)")
 args = ap.parse_args()
 n = 1 << args.log_gates
 variables, gates = synth.synthetic_circuit(args.log_gates, seed=1)
@@ -22,7 +23,8 @@ tables = synth.circuit_tables(variables, gates)
 pk = ProverKey(0)
 tau, gscal = synth.seeded_scalars(2, 7)
 total = 4 * n + 1
-pk.generate_srs_cyclic(tau, gscal, total, 0, args.world)
+log_block = args.log_block or synth.cyclic_log_block(args.log_gates)
+pk.generate_srs_cyclic(tau, gscal, total, 0, args.world, log_block=log_block)
 if args.world > 1:
     pk.set_sharding(0, args.world, lambda mine: np.broadcast_to(mine, (args.world,) + mine.shape))
 pk.set_opening_challenge(synth.to_mont([0x1234567890ABCDEF1122334455667788])[0])
@@ -36,5 +38,5 @@ for _ in range(args.steps):
     stage += pk.prove(inputs, blinds).seconds
 pk.ctx.sync()
 ms = (time.perf_counter() - t0) / args.steps * 1e3
-print(json.dumps({"world": args.world, "log_gates": args.log_gates, "ms_per_proof_one_rank": round(ms, 3),
+print(json.dumps({"world": args.world, "log_gates": args.log_gates, "log_block": log_block, "ms_per_proof_one_rank": round(ms, 3),
                   "stage_ms": {k: round(float(v) / args.steps * 1e3, 3) for k, v in zip(["round1_commit", "grand_product", "quotient", "open", "assemble", "total"], stage)}}))
