@@ -293,18 +293,10 @@ static PlonkProof prove_rounds(const KZGProverKey& pk, DeviceInputs& in, const s
     // the prover fails (:487).  Its commitment (three blinding terms, drawn here in the reference's rng order) is therefore
     // started now, beside z's, instead of after the divisibility check; a non-zero t would simply be committed again below.
     for (auto& r : blind[8]) r = rng();
+    // (z and t begun as one batch, sharing their launches when z is short enough for the narrow plan: 0.04 ms slower at 2^16 gates)
     int32_t z_ticket, t_ticket = -1;
-    {
-        // both in one call: when z is short enough for the narrow window plan the two share their launches
-        const void* p2[2] = {z_coeffs, in.work[4]};
-        const uint64_t l2[2] = {n, 0};
-        uint64_t b2[2][12];
-        int32_t t2[2];
-        memcpy(b2[0], &blind[7][0].v[0], 96);
-        memcpy(b2[1], &blind[8][0].v[0], 96);
-        check(ctx, plk_kzg_commit_begin_batch(ctx, 2, p2, l2, &b2[0][0], t2));
-        z_ticket = t2[0]; t_ticket = t2[1];
-    }
+    check(ctx, plk_kzg_commit_begin(ctx, z_coeffs, n, &blind[7][0].v[0], &z_ticket));
+    check(ctx, plk_kzg_commit_begin(ctx, in.work[4], 0, &blind[8][0].v[0], &t_ticket));
     lap(1);
 
     // ---- round 3: quotient t :224-259, on the detached compute stream.  The reductions of z and t (plk_kzg_submit) share that
