@@ -28,7 +28,7 @@ done
 # instruction-stream counters of the standalone 2^20-point MSM, and the figures bench.py quotes from these passes, tied to this build
 tools/sq_pass.sh $tag
 cp gpurun_out/sq_$tag.txt $out/msm20_pmc_sq.txt
-python3 tools/profile_current.py $out/bench20_pmc_FETCH_SIZE.txt $out/bench20_pmc_WRITE_SIZE.txt $out/msm20_pmc_sq.txt $out/bench20.json plonk_amd/lib/libplonk_hip.so $tag > $out/current.json
+python3 tools/profile_current.py $out/bench20_pmc_FETCH_SIZE.txt $out/bench20_pmc_WRITE_SIZE.txt $out/msm20_pmc_sq.txt $out/bench20.json plonk_amd/lib/libplonk_hip.so $tag 5 3 > $out/current.json
 find $out -name "*.db" -delete
 find $out -name "*kernel_trace.csv" -size +20M -delete
 echo done
