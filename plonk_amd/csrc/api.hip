@@ -662,6 +662,46 @@ static int32_t batch_buffers(plk_ctx* ctx) {
     PLK_HIP(hipHostMalloc(&ctx->batch_host, BATCH_WORDS * 4, hipHostMallocDefault));
     return PLK_OK;
 }
+// The MSMs of a round that is begun with one call, as launches: members whose share on this rank is short are put together, so
+// that a round of a sharded or small proof is a few launches instead of three per member, and its reductions one or two instead of
+// one per member (each costs about the same whatever the number of members, and they run one at a time).  Members on the wide plan
+// are taken in the order given and share a launch as long as it stays below WIDE_GROUP_ENTRIES sorted entries (about 0.6 ms of
+// accumulation: the reduction of one group hides beside the accumulation of the next); a long MSM stays alone.  The members on
+// the narrow plan form one group: where its first member stands when it is a few terms only (the two-coefficient s_id: its result
+// is there long before the round ends; enqueued last, its reduction would end the round behind everybody else's), behind the
+// others otherwise (they are the longer ones; measured at 2^16 gates: 4.02-4.05 ms per proof against 4.40 ms with the group in front).
+constexpr uint64_t WIDE_GROUP_ENTRIES = 9ull << 20;
+struct LaunchUnits {
+    uint32_t n = 0;
+    uint32_t size[MSM_SLOTS];
+    uint32_t member[MSM_SLOTS][MSM_SLOTS];
+    int plan[MSM_SLOTS];
+};
+static void plan_units(uint32_t count, const uint64_t* share, const int* plan, LaunchUnits* out) {
+    static const uint64_t group_entries = getenv("PLK_WIDE_GROUP_ENTRIES") ? strtoull(getenv("PLK_WIDE_GROUP_ENTRIES"), nullptr, 0) : WIDE_GROUP_ENTRIES;
+    uint32_t narrow[MSM_SLOTS], nn = 0, first_narrow = count;
+    uint64_t narrow_scalars = 0;
+    for (uint32_t k = 0; k < count; ++k) if (plan[k] != MSM_C) { if (!nn) first_narrow = k; narrow[nn++] = k; narrow_scalars += share[k]; }
+    const uint32_t narrow_pos = narrow_scalars <= 4096 ? first_narrow : count;
+    auto put_narrow = [&]() {
+        if (!nn) return;
+        out->plan[out->n] = MSM_C_SHORT; out->size[out->n] = nn;
+        for (uint32_t m = 0; m < nn; ++m) out->member[out->n][m] = narrow[m];
+        ++out->n;
+    };
+    out->n = 0;
+    int open = -1;                      // the unit that still takes wide members
+    uint64_t open_entries = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (k == narrow_pos) put_narrow();   // an open wide unit goes on taking members: it was begun before the narrow group and stays in front of it
+        if (plan[k] != MSM_C) continue;
+        const uint64_t e = share[k] * (uint64_t)MsmPlan<MSM_C>::WINDOWS;
+        if (open < 0 || open_entries + e > group_entries) { open = (int)out->n++; out->plan[open] = MSM_C; out->size[open] = 0; open_entries = 0; }
+        out->member[open][out->size[open]++] = k;
+        open_entries += e;
+    }
+    if (narrow_pos == count) put_narrow();
+}
 static int32_t commit_begin_on(plk_ctx* ctx, int si, hipStream_t lane, const void* coeffs_dev, uint64_t len, const uint64_t* blind, int idle_hint) {
     MsmSlot& s = ctx->slot[si];
     PLK_TRY(sort_after_compute(ctx, lane));
@@ -692,60 +732,44 @@ extern "C" int32_t plk_kzg_commit_begin_batch(plk_ctx* ctx, uint32_t count, cons
     uint32_t free_slots = 0;
     for (const auto& s : ctx->slot) free_slots += s.busy ? 0 : 1;
     if (free_slots < count) { ctx->err = "all MSM slots are busy: end an open ticket first"; return PLK_ERR_INVALID_ARG; }
-    // Members short enough for the narrow window plan share their launches: one sort and one accumulation for all of them, enqueued
-    // behind the others (whose launches are long enough to be worth having to themselves).  The blinding scalars of the group
-    // cross PCIe in one transfer.
+    // Members that are short on this rank share their launches (one sort, one accumulation, one reduction per group); the blinding
+    // scalars of a group cross PCIe in one transfer.
     PLK_TRY(batch_buffers(ctx));
-    uint32_t n_wide = 0;
-    for (uint32_t k = 0; k < count; ++k) n_wide += msm_plan_for(ctx, len[k], 0) == MSM_C ? 1 : 0;
-    uint8_t lanes[MSM_SLOTS];
-    plan_lanes(ctx, n_wide + (n_wide < count ? 1 : 0), "PLK_LANES_COMMIT", lanes);
     bool idle = ctx->reduce_pending.empty();
     for (const auto& s : ctx->slot) idle = idle && !s.busy;
-    MsmJob group[MSM_SLOTS];
-    uint32_t ng = 0, turn = 0;
     int32_t rc = PLK_OK;
-    // slots first, in the order given; the group's members are collected before anything is enqueued, because the group is
-    // enqueued where its first member stands (a two-coefficient polynomial begun second has its result long before the round ends;
-    // enqueued last, its reduction would end the round behind everybody else's)
     int si[MSM_SLOTS];
-    bool narrow[MSM_SLOTS];
+    uint64_t share[MSM_SLOTS];
+    int plan[MSM_SLOTS];
     for (uint32_t k = 0; k < count && rc == PLK_OK; ++k) {
         rc = msm_acquire_slot(ctx, &si[k]);
         if (rc != PLK_OK) break;
         tickets[k] = si[k];
         MsmSlot& s = ctx->slot[si[k]];
-        s.busy = true; s.kind = 1; s.in_batch = false;
-        narrow[k] = msm_plan_for(ctx, len[k], 0) != MSM_C;
-        if (!narrow[k]) continue;
-        s.in_batch = true;   // its blinding scalars sit in the batch's staging area until its sort has run
+        s.busy = true; s.kind = 1; s.in_batch = true;   // its blinding scalars sit in the batch's staging area until its sort has run
         ++ctx->batch_open;
-        memcpy(ctx->batch_host + BATCH_BLIND + 24 * ng, blind + 12 * k, 96);
-        group[ng].slot = si[k]; group[ng].scalars = (const uint32_t*)coeffs_dev[k]; group[ng].k = len[k]; group[ng].base_offset = 0;
-        group[ng].n_blind = 3; group[ng].blind_dev = ctx->batch_dev + BATCH_BLIND + 24 * ng;
-        ++ng;
+        share[k] = msm_share(ctx, len[k], 0);
+        plan[k] = msm_plan_for(ctx, len[k], 0);
     }
-    // Where the group goes: a group of a few terms (the two-coefficient s_id) where its first member stands, so that its result is
-    // there long before the round ends (enqueued last, its reduction would end the round behind everybody else's); a group with
-    // real work behind the members that have launches to themselves, which are the longer ones (measured at 2^16 gates: 4.02-4.05 ms
-    // per proof against 4.40 ms with the group in front).
-    uint64_t group_scalars = 0;
-    for (uint32_t g = 0; g < ng; ++g) group_scalars += group[g].k;
-    uint32_t group_pos = count;
-    if (group_scalars <= 4096) for (uint32_t k = count; k-- > 0;) if (narrow[k]) group_pos = k;
-    bool first = true;
-    for (uint32_t k = 0; k <= count && rc == PLK_OK; ++k) {
-        if (k == group_pos && ng) {
-            hipStream_t lane = lanes[turn] ? ctx->st_red : ctx->st_sort;
-            rc = sort_after_compute(ctx, lane);
-            if (rc == PLK_OK && hipMemcpyAsync(ctx->batch_dev + BATCH_BLIND, ctx->batch_host + BATCH_BLIND, (size_t)ng * 96, hipMemcpyHostToDevice, lane) != hipSuccess) rc = PLK_ERR_HIP;
-            if (rc == PLK_OK) rc = msm_enqueue_group(ctx, group, ng, lane, (idle && first) ? 1 : 0, MSM_C_SHORT);
-            ++turn; first = false;
+    LaunchUnits units;
+    if (rc == PLK_OK) plan_units(count, share, plan, &units);
+    uint8_t lanes[MSM_SLOTS];
+    plan_lanes(ctx, units.n, "PLK_LANES_COMMIT", lanes);
+    uint32_t staged = 0;
+    for (uint32_t u = 0; u < units.n && rc == PLK_OK; ++u) {
+        MsmJob jobs[MSM_SLOTS];
+        const uint32_t first_staged = staged;
+        for (uint32_t m = 0; m < units.size[u]; ++m, ++staged) {
+            const uint32_t k = units.member[u][m];
+            memcpy(ctx->batch_host + BATCH_BLIND + 24 * staged, blind + 12 * k, 96);
+            jobs[m].slot = si[k]; jobs[m].scalars = (const uint32_t*)coeffs_dev[k]; jobs[m].k = len[k]; jobs[m].base_offset = 0;
+            jobs[m].n_blind = 3; jobs[m].blind_dev = ctx->batch_dev + BATCH_BLIND + 24 * staged;
         }
-        if (k == count || narrow[k] || rc != PLK_OK) continue;
-        hipStream_t lane = lanes[turn] ? ctx->st_red : ctx->st_sort;
-        rc = commit_begin_on(ctx, si[k], lane, coeffs_dev[k], len[k], blind + 12 * k, (idle && first) ? 1 : 0);
-        ++turn; first = false;
+        hipStream_t lane = lanes[u] ? ctx->st_red : ctx->st_sort;
+        rc = sort_after_compute(ctx, lane);
+        if (rc == PLK_OK && hipMemcpyAsync(ctx->batch_dev + BATCH_BLIND + 24 * first_staged, ctx->batch_host + BATCH_BLIND + 24 * first_staged,
+                                           (size_t)units.size[u] * 96, hipMemcpyHostToDevice, lane) != hipSuccess) rc = PLK_ERR_HIP;
+        if (rc == PLK_OK) rc = msm_enqueue_group(ctx, jobs, units.size[u], lane, (idle && u == 0) ? 1 : 0, units.plan[u]);
     }
     if (rc != PLK_OK) { (void)plk_kzg_cancel(ctx); return rc; }   // the members begun so far are given up with everything else that is open
     return PLK_OK;
@@ -820,7 +844,7 @@ extern "C" int32_t plk_kzg_commit(plk_ctx* ctx, const uint64_t* coeffs_host, uin
 
 // ---- KZG open --------------------------------------------------------------------------------------
 // hiding part of an opening, on the host: r' = challenge * r (3 coefficients), r'/(X - zeta) has 2 (-> hw, 16 words), random_v = r'(zeta)
-constexpr uint64_t BATCH_DIVISION_BELOW = (1ull << 19) + 1;   // rounds whose longest polynomial is shorter get their divisions as one batch
+constexpr uint64_t BATCH_DIVISION_BELOW = (1ull << 19) + 1;   // rounds whose longest MSM (on this rank) is shorter get their divisions as one batch
 static void hiding_part(const uint64_t* blind, const uint64_t zeta[4], const uint64_t challenge[4], uint64_t random_v[4], uint32_t* hw) {
     using namespace host;
     const el z = el_load(zeta), ch = el_load(challenge);
@@ -879,9 +903,11 @@ extern "C" int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const 
     bool idle = ctx->reduce_pending.empty();
     for (const auto& s : ctx->slot) { free_slots += s.busy ? 0 : 1; idle = idle && !s.busy; }
     if (free_slots < count) { ctx->err = "all MSM slots are busy: end an open ticket first"; return PLK_ERR_INVALID_ARG; }
+    // what decides is the length of this rank's MSMs: a rank of a sharded proof divides whole polynomials and accumulates its share
     uint64_t longest = 0;
-    for (uint32_t k = 0; k < count; ++k) longest = std::max(longest, len[k]);
-    if (longest >= BATCH_DIVISION_BELOW) {
+    for (uint32_t k = 0; k < count; ++k) longest = std::max(longest, msm_share(ctx, len[k] >= 2 ? len[k] - 1 : 0, 0));
+    static const uint64_t batch_below = getenv("PLK_BATCH_DIV_BELOW") ? strtoull(getenv("PLK_BATCH_DIV_BELOW"), nullptr, 0) : BATCH_DIVISION_BELOW;
+    if (longest >= batch_below) {
         uint8_t lanes[MSM_SLOTS];
         plan_lanes(ctx, count, "PLK_LANES_OPEN", lanes);
         for (uint32_t k = 0; k < count; ++k) {
@@ -916,47 +942,33 @@ extern "C" int32_t plk_kzg_open_begin_batch(plk_ctx* ctx, uint32_t count, const 
         hiding_part(blind + 12 * k, zeta, challenge, s.host_rv, hw_host + 16 * k);
         s.eval_host = res_host + 8 * k;
     }
-    // All divisions as one batch on the first front stream (polynomials this short: latency and nothing else), then the sorts:
-    // members on the wide window plan one by one on alternating front streams, the members short enough for the narrow plan as
-    // one group that shares its launches.
+    // All divisions as one batch on the first front stream (polynomials this short: latency and nothing else), then the sorts,
+    // in groups that share their launches (plan_units), on alternating front streams.
     hipStream_t st0 = ctx->st_sort;
     if (rc == PLK_OK && !ctx->detached) rc = order_streams(ctx, ctx->stream, st0);
     if (rc == PLK_OK && hipMemcpyAsync(hw_dev, hw_host, (size_t)count * 64, hipMemcpyHostToDevice, st0) != hipSuccess) rc = PLK_ERR_HIP;
     if (rc == PLK_OK) rc = division_enqueue_batch(ctx, st0, count, jobs, zeta, challenge);
     if (rc == PLK_OK && hipMemcpyAsync(res_host, res_dev, (size_t)count * 32, hipMemcpyDeviceToHost, st0) != hipSuccess) rc = PLK_ERR_HIP;
-    MsmJob group[MSM_SLOTS];
-    uint32_t ng = 0;
-    bool narrow[MSM_SLOTS];
+    uint64_t share[MSM_SLOTS];
+    int plan[MSM_SLOTS];
     for (uint32_t k = 0; k < count && rc == PLK_OK; ++k) {
-        MsmSlot& s = ctx->slot[si[k]];
         const uint64_t scalars = len[k] >= 2 ? len[k] - 1 : 0;
         tickets[k] = si[k];
-        narrow[k] = msm_plan_for(ctx, scalars, 0) == MSM_C_SHORT;
-        if (!narrow[k]) continue;
-        group[ng].slot = si[k]; group[ng].scalars = s.scal_dev; group[ng].k = scalars; group[ng].base_offset = 0;
-        group[ng].n_blind = 2; group[ng].blind_dev = hw_dev + 16 * k;
-        ++ng;
+        share[k] = msm_share(ctx, scalars, 0);
+        plan[k] = msm_plan_for(ctx, scalars, 0);
     }
-    // the group goes where its first member stands when it is a few terms only, behind the members with launches of their own otherwise
-    // (see plk_kzg_commit_begin_batch)
-    uint64_t group_scalars = 0;
-    for (uint32_t g = 0; g < ng; ++g) group_scalars += group[g].k;
-    uint32_t group_pos = count;
-    if (group_scalars <= 4096) for (uint32_t k = count; k-- > 0;) if (narrow[k]) group_pos = k;
-    bool first = true;
-    for (uint32_t k = 0; k <= count && rc == PLK_OK; ++k) {
-        if (k == group_pos && ng) {
-            hipStream_t lane = front_lane(ctx);
-            rc = sort_after_compute(ctx, lane);   // the second front stream waits for the divisions (and the sorts before this one)
-            if (rc == PLK_OK) rc = msm_enqueue_group(ctx, group, ng, lane, (idle && first) ? 1 : 0, MSM_C_SHORT);
-            first = false;
+    LaunchUnits units;
+    if (rc == PLK_OK) plan_units(count, share, plan, &units);
+    for (uint32_t u = 0; u < units.n && rc == PLK_OK; ++u) {
+        MsmJob jobs[MSM_SLOTS];
+        for (uint32_t m = 0; m < units.size[u]; ++m) {
+            const uint32_t k = units.member[u][m];
+            jobs[m].slot = si[k]; jobs[m].scalars = ctx->slot[si[k]].scal_dev; jobs[m].k = len[k] >= 2 ? len[k] - 1 : 0; jobs[m].base_offset = 0;
+            jobs[m].n_blind = 2; jobs[m].blind_dev = hw_dev + 16 * k;
         }
-        if (k == count || narrow[k] || rc != PLK_OK) continue;
-        MsmSlot& s = ctx->slot[si[k]];
         hipStream_t lane = front_lane(ctx);
-        rc = sort_after_compute(ctx, lane);
-        if (rc == PLK_OK) rc = msm_enqueue(ctx, s, s.scal_dev, len[k] >= 2 ? len[k] - 1 : 0, 0, 2, lane, (idle && first) ? 1 : 0, hw_dev + 16 * k);
-        first = false;
+        rc = sort_after_compute(ctx, lane);   // the second front stream waits for the divisions (and the sorts before this one)
+        if (rc == PLK_OK) rc = msm_enqueue_group(ctx, jobs, units.size[u], lane, (idle && u == 0) ? 1 : 0, units.plan[u]);
     }
     if (rc != PLK_OK) {   // what was enqueued runs to completion on buffers that stay valid; the slots are handed back
         (void)hipStreamSynchronize(ctx->st_sort); (void)hipStreamSynchronize(ctx->st_red);

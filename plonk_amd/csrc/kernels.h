@@ -26,6 +26,7 @@ struct MsmJob {
     const uint32_t* blind_dev;   // null: the slot's own buffer
 };
 int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset);   // MSM_C or MSM_C_SHORT
+uint64_t msm_share(const plk_ctx* ctx, uint64_t k, uint64_t base_offset);   // scalars of that range on this rank
 int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStream_t lane, int idle_hint, int plan_c);
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);
 // the host tail of an MSM in independent pieces (for several host threads) and their combination

@@ -673,6 +673,12 @@ static void clip_to_shard(const plk_ctx* ctx, const uint32_t* scalars, uint64_t 
     seg->count = (uint32_t)(hi - lo);
     seg->table_off = (uint32_t)(lo - slo);
 }
+// Scalars of the global range [base_offset, base_offset + k) that fall to this context's shard.
+uint64_t msm_share(const plk_ctx* ctx, uint64_t k, uint64_t base_offset) {
+    MsmSeg seg;
+    clip_to_shard(ctx, nullptr, k, base_offset, &seg);
+    return seg.count;
+}
 // Window width for the MSM over the global range [base_offset, base_offset + k): the narrow plan when this rank's share is short
 // and lies inside the prefix of the SRS that the narrow tables cover.
 int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset) {
@@ -884,53 +890,76 @@ static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group, bo
     for (int i = 0; i < rb.n; ++i) ctx->slot[group[i]].done_owner = group[0];
     return PLK_OK;
 }
+// Which MSMs share a reduction launch.  All results of a round are asked for together, so what counts is when the last reduction
+// ends: a launch costs about the same for one member as for ten, and the reduction stream runs one launch at a time.  The
+// accumulation launches are replayed on a model of the device (two streams that share the chip, a kernel's time proportional to its
+// entries), then the reduction stream: whenever it is free, everything whose accumulation is over by then goes into one launch
+// (per window plan: a launch is compiled for one bucket count).  Long MSMs (a proof of 2^20 gates on one GPU) still get a launch
+// each, beside the accumulations that follow; the short MSMs of a sharded or small proof, which finish while the previous
+// reduction is running, share one (measured on one rank of eight at 2^20 gates: three reductions one after the other at the end of
+// every round before, one or two now).
 int32_t msm_flush_reductions(plk_ctx* ctx) {
     if (ctx->reduce_pending.empty()) return PLK_OK;
-    std::vector<std::pair<double, int>> order;
-    double stream_free[2] = {0, 0};
-    int last_owner = -1;
+    // accumulation launches in the order they were enqueued (the members of a batch share one)
+    struct Launch { int owner; int stream; double work; double finish; };
+    std::vector<Launch> launches;
     for (int si : ctx->reduce_pending) {
         const MsmSlot& s = ctx->slot[si];
-        // the members of a batch finish together: their launch is counted once, with the entries of all of them
-        if (s.ev_owner != last_owner) {
-            double group_entries = 0;
-            for (int sj : ctx->reduce_pending) if (ctx->slot[sj].ev_owner == s.ev_owner) group_entries += (double)ctx->slot[sj].max_entries;
-            stream_free[s.acc_stream] += group_entries + 65536.0;   // a launch costs something even when it is empty
-            last_owner = s.ev_owner;
+        if (launches.empty() || launches.back().owner != s.ev_owner) launches.push_back({s.ev_owner, s.acc_stream, 65536.0, 0.0});   // a launch costs something even when it is empty
+        launches.back().work += (double)s.max_entries;
+    }
+    {
+        std::vector<size_t> queue[2];
+        for (size_t i = 0; i < launches.size(); ++i) queue[launches[i].stream].push_back(i);
+        size_t head[2] = {0, 0};
+        double rem[2] = {queue[0].empty() ? 0 : launches[queue[0][0]].work, queue[1].empty() ? 0 : launches[queue[1][0]].work}, t = 0;
+        for (;;) {
+            const bool a0 = head[0] < queue[0].size(), a1 = head[1] < queue[1].size();
+            if (!a0 && !a1) break;
+            const int active = (a0 ? 1 : 0) + (a1 ? 1 : 0);
+            const double step = a0 && a1 ? std::min(rem[0], rem[1]) : (a0 ? rem[0] : rem[1]);   // progress of every running kernel
+            t += step * active;
+            for (int q = 0; q < 2; ++q) {
+                if (head[q] >= queue[q].size()) continue;
+                rem[q] -= step;
+                if (rem[q] <= 1e-6) {
+                    launches[queue[q][head[q]]].finish = t;
+                    if (++head[q] < queue[q].size()) rem[q] = launches[queue[q][head[q]]].work;
+                }
+            }
         }
-        order.push_back({stream_free[s.acc_stream], si});
+    }
+    struct Item { double finish; int slot; };
+    std::vector<Item> pending;
+    double last_finish = 0;
+    for (int si : ctx->reduce_pending) {
+        for (const auto& l : launches) if (l.owner == ctx->slot[si].ev_owner) { pending.push_back({l.finish, si}); last_finish = std::max(last_finish, l.finish); break; }
     }
     ctx->reduce_pending.clear();
-    std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
-    // neighbours in that order share a launch as long as their accumulations together take well under a millisecond (and they use
-    // the same window plan: a launch is compiled for one bucket count)
-    constexpr uint64_t GROUP_ENTRIES = 12ull << 20;
-    struct Group { std::vector<int> slots; uint64_t entries = 0; double finish = 0; };
-    std::vector<Group> all;
-    // the two window plans form their groups separately (a two-coefficient polynomial on the narrow plan must not cut a run of
-    // long MSMs on the wide plan into two launches); the groups are then taken in the order in which their last members finish
-    for (int plan : {MSM_C, MSM_C_SHORT}) {
-        bool open = false;
-        for (const auto& o : order) {
-            if (ctx->slot[o.second].plan_c != plan) continue;
-            const uint64_t e = ctx->slot[o.second].max_entries;
-            if (!open || all.back().entries + e > GROUP_ENTRIES) { all.emplace_back(); open = true; }
-            all.back().slots.push_back(o.second);
-            all.back().entries += e;
-            all.back().finish = o.first;
+    std::stable_sort(pending.begin(), pending.end(), [](const Item& x, const Item& y) { return x.finish < y.finish; });
+    // in units of accumulated entries (about 14 per nanosecond): a reduction beside accumulation kernels 0.35 ms on the wide plan,
+    // 0.1 ms on the narrow one; an MSM that finishes within 0.05 ms of the launch is waited for
+    constexpr double REDUCE_WIDE = 5.0e6, REDUCE_NARROW = 1.5e6, SLACK = 0.7e6;
+    double red_free = 0;
+    while (!pending.empty()) {
+        const double start = std::max(red_free, pending[0].finish);
+        const int plan = ctx->slot[pending[0].slot].plan_c;
+        const double cost = plan == MSM_C_SHORT ? REDUCE_NARROW : REDUCE_WIDE;
+        // when everything still outstanding is over before a launch begun now would be, one launch for all of it ends sooner than two
+        const double reach = last_finish <= start + cost ? cost : SLACK;
+        std::vector<int> group;
+        std::vector<Item> rest;
+        double ready = start;
+        for (const auto& it : pending) {
+            if (it.finish <= start + reach && ctx->slot[it.slot].plan_c == plan) { group.push_back(it.slot); ready = std::max(ready, it.finish); }
+            else rest.push_back(it);
         }
+        // nothing is accumulating any more when this launch starts: the builds without a register limit
+        const bool tail = last_finish <= ready + SLACK;
+        PLK_TRY(enqueue_reduction(ctx, group, tail));
+        red_free = ready + cost;
+        pending.swap(rest);
     }
-    std::stable_sort(all.begin(), all.end(), [](const Group& x, const Group& y) { return x.finish < y.finish; });
-    std::vector<std::vector<int>> groups;
-    std::vector<uint64_t> entries_of;
-    for (auto& g : all) { groups.push_back(g.slots); entries_of.push_back(g.entries); }
-    // The last group to finish ends the batch and gets the builds without a register limit: nothing else is running then.  So does a
-    // group that is followed by next to nothing (the handful of entries of a two-coefficient polynomial, which sit in a group of
-    // their own when they use the other window plan): the accumulations behind it are over before its reduction has started.
-    uint64_t later = 0;
-    std::vector<bool> tail(groups.size(), false);
-    for (size_t g = groups.size(); g-- > 0;) { tail[g] = later < (1ull << 16); later += entries_of[g]; }
-    for (size_t g = 0; g < groups.size(); ++g) PLK_TRY(enqueue_reduction(ctx, groups[g], tail[g]));
     return PLK_OK;
 }
 

@@ -203,13 +203,20 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(DivBatch db, uint32_t
     __shared__ uint32_t lds[2 * DIV_THREADS * 9];
     __shared__ uint32_t heads[DIV_THREADS * 9];
     const uint32_t mb = member0 + blockIdx.y;
-    if (blockIdx.x >= db.apply_blocks[mb]) return;
+    if (blockIdx.x >= ((db.apply_blocks[mb] + 7) & ~7u)) return;
     const uint32_t* __restrict__ c = db.c[mb];
     const uint32_t* __restrict__ carry = db.carry[mb];
     uint32_t* __restrict__ q_out = db.q_out[mb];
     const uint64_t len = db.len[mb];
     const uint32_t cyc_world = db.cyc_world, cyc_rank = db.cyc_rank, cyc_log_block = db.cyc_log_block;
-    const uint32_t t = threadIdx.x, blk = db.first_block[mb] + blockIdx.x;
+    // Consecutive workgroups go to different XCDs (eight of them), and on a block-cyclic shard only every world-th stretch of blocks
+    // has work: taken in order, the working blocks of an eight-rank shard all land on one or two XCDs.  The grid is therefore walked
+    // column by column: workgroup i takes block (i mod 8) * ceil(blocks / 8) + i / 8.
+    // (Only there: with work in every block the plain order is the better one, neighbouring workgroups read neighbouring memory.)
+    const uint32_t per_xcd = (db.apply_blocks[mb] + 7) >> 3;
+    const uint32_t rel = db.cyc_world > 1 ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (rel >= db.apply_blocks[mb]) return;
+    const uint32_t t = threadIdx.x, blk = db.first_block[mb] + rel;
     // A workgroup writes the quotient coefficients k in [blk BLOCK, (blk + 1) BLOCK): q_k = scale h_(k+1), so the last one is the
     // block's carry (h at the first coefficient of the next block) and the first coefficient's own h belongs to the block before.
     // Aligned like this, the division blocks coincide with the blocks of a block-cyclic SRS shard of the same or a larger size.
@@ -270,17 +277,22 @@ int32_t division_enqueue_batch(plk_ctx* ctx, hipStream_t st, uint32_t count, con
     db.scale = w8_of(scale ? scale : host::FR.one);
     db.cyc_world = ctx->cyc_world; db.cyc_rank = ctx->cyc_rank; db.cyc_log_block = ctx->cyc_log_block;
     uint32_t n_short = 0, n = 0, max_nb[2] = {0, 0}, max_apply[2] = {0, 0};
+    // A batch of several long polynomials fills the chip whatever the block size, and then the work per coefficient decides (the
+    // scan over a block costs sixteen products per thread, whatever L): the long form from 2^19 coefficients on.
+    static const int batch_long_log = getenv("PLK_DIV_BATCH_LONG_FROM_LOG") ? atoi(getenv("PLK_DIV_BATCH_LONG_FROM_LOG")) : 19;
+    const uint64_t long_from = count >= 4 ? std::min<uint64_t>(DIV_LONG_FROM, 1ull << batch_long_log) : DIV_LONG_FROM;
     for (int cls = 0; cls < 2; ++cls) {
         for (uint32_t k = 0; k < count; ++k) {
             const DivJob& j = jobs[k];
-            const bool is_short = div_log_l(j.len) == DIV_LOG_L_SHORT;
+            const bool is_short = j.len < long_from;
             if (is_short != (cls == 0)) continue;
-            const uint64_t block = div_block(j.len);
+            const int log_l = is_short ? DIV_LOG_L_SHORT : DIV_LOG_L_LONG;
+            const uint64_t block = (uint64_t)DIV_THREADS << log_l;
             const uint32_t nb = (uint32_t)((j.len + block - 1) / block);
             db.c[n] = j.coeffs; db.len[n] = j.len; db.nb[n] = nb;
             db.A[n] = j.work; db.carry[n] = j.work + (size_t)(nb + 1) * 8;
             db.q_out[n] = j.q_out; db.h0_out[n] = j.h0_out;
-            db.log_block[n] = 8 + (uint32_t)div_log_l(j.len);
+            db.log_block[n] = 8 + (uint32_t)log_l;
             db.first_block[n] = 0; db.apply_blocks[n] = 0;
             if (j.q_out && j.len > 1 && j.q_count > 0) {
                 // block b writes q_out[k] for k in [b block, (b + 1) block): only the blocks that hold k = q_first .. q_first + q_count - 1 are walked
@@ -301,8 +313,8 @@ int32_t division_enqueue_batch(plk_ctx* ctx, hipStream_t st, uint32_t count, con
     if (n_short && max_nb[0]) hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_SHORT>, dim3(max_nb[0], n_short), dim3(DIV_THREADS), 0, st, db, 0u);
     if (n_long && max_nb[1]) hipLaunchKernelGGL(k_div_sums<DIV_LOG_L_LONG>, dim3(max_nb[1], n_long), dim3(DIV_THREADS), 0, st, db, n_short);
     hipLaunchKernelGGL(k_div_carries, dim3(n), dim3(DIV_THREADS), 0, st, db);
-    if (n_short && max_apply[0]) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_SHORT>, dim3(max_apply[0], n_short), dim3(DIV_THREADS), 0, st, db, 0u);
-    if (n_long && max_apply[1]) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_LONG>, dim3(max_apply[1], n_long), dim3(DIV_THREADS), 0, st, db, n_short);
+    if (n_short && max_apply[0]) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_SHORT>, dim3((max_apply[0] + 7) & ~7u, n_short), dim3(DIV_THREADS), 0, st, db, 0u);
+    if (n_long && max_apply[1]) hipLaunchKernelGGL(k_div_apply<DIV_LOG_L_LONG>, dim3((max_apply[1] + 7) & ~7u, n_long), dim3(DIV_THREADS), 0, st, db, n_short);
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
     return PLK_OK;
