@@ -450,6 +450,33 @@ def test_open_batch_matches_single_openings_and_the_oracle(orc):
         assert batch[i][1] == single[1] and all(np.array_equal(x, y) for x, y in zip((batch[i][0], batch[i][2], batch[i][3]), (single[0], single[2], single[3]))), lengths[i]
         assert np.array_equal(batch[i][3], orc.poly_eval(polys[i], zeta)), lengths[i]
         c.free(d)
+    # Lengths between the narrow plan's limit and the limit for batched divisions: the members on the wide plan share their
+    # launches in groups, beside the narrow group.  Checked through the trapdoor of this SRS (tau, gamma are known here):
+    # W = ch * [(f(tau) - f(zeta)) + gamma (r(tau) - r(zeta))] / (tau - zeta) * G, evaluations by the oracle's Horner rule.
+    lengths = [100000, 131072, 262144, 70001, 300000, 5, 65536]
+    polys = [residues(k, 6000 + i) for i, k in enumerate(lengths)]
+    blinds = np.stack([rand_fr(orc, 3, 6100 + i) for i in range(len(lengths))])
+    devs = [c.upload(p) for p in polys]
+    rmod = pm.R_MOD
+    z_i, ch_i = orc.fr_to_ints(zeta)[0], orc.fr_to_ints(chal)[0]
+    inv_d = pow((TAU - z_i) % rmod, rmod - 2, rmod)
+    for rep in range(2):
+        tickets = c.open_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12), zeta, chal)
+        for i in (3, 0, 6, 2, 5, 1, 4):
+            w, winf, rv, ev = c.open_end(tickets[i])
+            f_tau, f_z = orc.fr_to_ints(orc.poly_eval(polys[i], tau))[0], orc.fr_to_ints(orc.poly_eval(polys[i], zeta))[0]
+            b_tau, b_z = orc.fr_to_ints(orc.poly_eval(blinds[i], tau))[0], orc.fr_to_ints(orc.poly_eval(blinds[i], zeta))[0]
+            k = ch_i * ((f_tau - f_z) + GSCAL * (b_tau - b_z)) % rmod * inv_d % rmod
+            assert orc.point_to_ints(w, winf) == (pm.g1_mul(k, pm.G1_GEN) if k else None), lengths[i]
+            assert orc.fr_to_ints(ev)[0] == f_z and orc.fr_to_ints(rv)[0] == ch_i * b_z % rmod, lengths[i]
+    # the same polynomials as commitments begun with one call: C = (f(tau) + gamma r(tau)) G
+    tickets = c.commit_begin_batch(devs, lengths, blinds.reshape(len(lengths), 12))
+    pts, inf, _, _ = c.end_many(tickets)
+    for i in range(len(lengths)):
+        k = (orc.fr_to_ints(orc.poly_eval(polys[i], tau))[0] + GSCAL * orc.fr_to_ints(orc.poly_eval(blinds[i], tau))[0]) % rmod
+        assert orc.point_to_ints(pts[i, :8], inf[i]) == pm.g1_mul(k, pm.G1_GEN), lengths[i]
+    for d in devs:
+        c.free(d)
     c.close()
 
 
