@@ -21,7 +21,6 @@ sys.path.insert(0, ROOT)
 
 MAD_PEAK = 33.3e12          # v_mad_u64_u32 lane-ops/s measured on MI355X by tools/valu_microbench (profiles/valu_microbench_r01.txt)
 HBM_PEAK = 8.0e12
-WINDOWS = 16                # 16-bit signed windows over 254-bit scalars
 MODMUL_PER_MADD = 10        # XYZZ mixed addition: 8 M + 2 S
 MADS_PER_MODMUL = 136       # 8x8 + 8x8 + 8 multiply-adds of an 8x32-bit-limb Montgomery product (the algorithmic count)
 ACC_ALGO_BYTES_PER_ENTRY = 68.0   # 64 B table point + 4 B sorted entry gathered per (pair, window)
@@ -332,13 +331,22 @@ def main():
     launches_per_proof = max(1, acc_launches // max(1, args.steps))
     avg_launch_ms = acc_ms / max(1, acc_launches)
     pairs_per_launch = pairs_per_proof / launches_per_proof
-    mads_per_pair = WINDOWS * MODMUL_PER_MADD * MADS_PER_MODMUL
-    mads_per_launch = pairs_per_launch * mads_per_pair
+    # Mixed additions per proof: every scalar of an MSM costs one per window of the plan the library uses at that length (15 windows
+    # of 17 bits for long MSMs, 16 of 16 bits, 20 of 13 bits for short ones; plk_msm_plan_query).  The MSMs of a proof: commitments
+    # to the seven circuit polynomials, z and t (three blinding terms each), then their nine openings (one coefficient fewer, two
+    # hiding terms); t is the zero polynomial for a satisfied circuit.
+    poly_lens = [len(p) for p in inputs.polys] + [n, 0]
+    msm_lens = [(l, 3) for l in poly_lens] + [(max(l - 1, 0), 2) for l in poly_lens]
+    entries_per_proof = sum((l + b) * pk.ctx.msm_plan(l)[1] for l, b in msm_lens) / world
+    windows_avg = entries_per_proof / (sum(l + b for l, b in msm_lens) / world)
+    entries_per_launch = entries_per_proof / launches_per_proof
+    mads_per_entry = MODMUL_PER_MADD * MADS_PER_MODMUL
+    mads_per_launch = entries_per_launch * mads_per_entry
     achieved = mads_per_launch / (avg_launch_ms * 1e-3) if avg_launch_ms > 0 else 0.0
     # Consecutive launches alternate between two streams and overlap, so a launch's own duration includes the time it shares the
     # chip with its neighbour.  "busy" is the time at least one launch was running; the isolated figure below times launches
     # of one 2^k-coefficient commitment with nothing else on the device (outside the timed region, not part of `value`).
-    achieved_busy = pairs_per_proof * args.steps * mads_per_pair / (acc_busy_ms * 1e-3) if acc_busy_ms > 0 else 0.0
+    achieved_busy = entries_per_proof * args.steps * mads_per_entry / (acc_busy_ms * 1e-3) if acc_busy_ms > 0 else 0.0
     pk.ctx.profile_reset()
     iso_reps = 3
     iso_poly = np.ascontiguousarray(inputs.polys[0])
@@ -353,28 +361,29 @@ def main():
     iso_ms, iso_n = pk.ctx.profile_get("msm_accumulate")
     iso_launch_ms = iso_ms / max(1, iso_n)
     iso_pairs = len(iso_poly) // world + (3 if rank == 0 else 0)
-    achieved_iso = iso_pairs * mads_per_pair / (iso_launch_ms * 1e-3) if iso_launch_ms > 0 else 0.0
+    iso_windows = pk.ctx.msm_plan(len(iso_poly))[1]
+    achieved_iso = iso_pairs * iso_windows * mads_per_entry / (iso_launch_ms * 1e-3) if iso_launch_ms > 0 else 0.0
     pk.ctx.profile_enable(False)
     bytes_per_launch = pairs_per_launch * 96.0
     derived = profile_derived()
     acc_prof = (derived or {}).get("k_msm_accumulate")
-    traffic_per_launch = pairs_per_launch * WINDOWS * acc_prof["traffic_bytes_per_entry"] if acc_prof else None
+    traffic_per_launch = entries_per_launch * acc_prof["traffic_bytes_per_entry"] if acc_prof else None
     # The object leads with the figure that fits inside ms_per_step: algorithmic multiply-adds of the whole proof over the time at
     # least one accumulation kernel was running.  The per-launch figure (algorithmic work of one launch over its own duration, what
     # rocprofv3 reports as the kernel's average) follows as a sub-field: two launches overlap nearly all the time, so each sees half
     # a chip and its duration counts the shared time twice.
     roofline = {
         "kernel": "k_msm_accumulate", "bound": "valu_int", "achieved": round(achieved_busy / 1e12, 3), "peak": MAD_PEAK / 1e12,
-        "unit": "T mad/s (algorithmic 32-bit multiply-adds: pairs x 16 windows x 10 modmul x 136)", "frac": round(achieved_busy / MAD_PEAK, 4),
+        "unit": "T mad/s (algorithmic 32-bit multiply-adds: pairs x windows of the plan in use x 10 modmul x 136)", "windows_per_pair_avg": round(windows_avg, 3), "frac": round(achieved_busy / MAD_PEAK, 4),
         "basis": "busy time: all launches of a proof over the time at least one of them was running (HIP events on their streams)",
         "busy_ms_per_proof": round(acc_busy_ms / args.steps, 3),
         "traffic": round(traffic_per_launch) if traffic_per_launch is not None else None,
-        "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE of this command, profiles/current.json); algorithmic: %d" % round(pairs_per_launch * WINDOWS * ACC_ALGO_BYTES_PER_ENTRY),
+        "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE of this command, profiles/current.json); algorithmic: %d" % round(entries_per_launch * ACC_ALGO_BYTES_PER_ENTRY),
         "per_launch": {"note": "algorithmic work of one launch over its own duration; launches alternate between two streams and overlap",
                        "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_proof": int(launches_per_proof), "pairs_per_launch_avg": int(pairs_per_launch),
                        "achieved": round(achieved / 1e12, 3), "frac": round(achieved / MAD_PEAK, 4)},
         "isolated": {"note": "one commitment of 2^%d coefficients at a time, outside the timed region" % log_n, "avg_launch_ms": round(iso_launch_ms, 4),
-                     "pairs": int(iso_pairs), "achieved": round(achieved_iso / 1e12, 3), "frac": round(achieved_iso / MAD_PEAK, 4)},
+                     "pairs": int(iso_pairs), "windows": iso_windows, "achieved": round(achieved_iso / 1e12, 3), "frac": round(achieved_iso / MAD_PEAK, 4)},
         "hbm": {"bound": "hbm", "achieved": round(bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else 0.0, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(bytes_per_launch / (avg_launch_ms * 1e-3) / HBM_PEAK, 4) if avg_launch_ms > 0 else 0.0, "bytes_per_pair": 96,
                 "traffic_GBps": round(traffic_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 and traffic_per_launch is not None else None},
@@ -394,7 +403,7 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "synthetic 2^%d-gate random arithmetic circuit, BN254, hiding KZG10, full proof (BASELINE.json configs[2])" % log_n,
-                   "log_gates": log_n, "srs_points": total, "msm_pairs_per_proof": 20 * n + 45, "ntt_per_proof": 4,
+                   "log_gates": log_n, "srs_points": total, "msm_pairs_per_proof": 20 * n + 45, "msm_additions_per_proof": int(round(entries_per_proof * world)), "ntt_per_proof": 4,
                    "parallelism": "1 GPU" if world == 1 else "MSM sharded over %d GPUs by block-cyclic point ranges (%d points per block), partial sums exchanged by %s; other rounds replicated" % (world, 1 << log_block, collective)},
         "msm_gpts_per_s": round((20 * n + 45) / (ms_per_step * 1e-3) / 1e9, 4),
         "stage_ms": {k: round(float(v) / args.steps * 1e3, 3) for k, v in zip(["round1_commit", "grand_product", "quotient", "open", "assemble", "total"], stage)},

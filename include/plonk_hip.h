@@ -99,6 +99,10 @@ int32_t plk_msm_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k, uint64_t 
  * ZZ = 0 is the identity), 16 limbs.  plk_g1_sum_partials adds such partials and normalises. */
 int32_t plk_msm_partial_dev(plk_ctx* ctx, const void* scalars_dev, uint64_t k, uint64_t base_offset, uint64_t out_xyzz[16]);
 int32_t plk_g1_sum_partials(const uint64_t* xyzz, uint64_t count, uint64_t out_xy[8], int32_t* out_is_inf);
+/* The window layout this context would use for the MSM over [base_offset, base_offset + k) (no counterpart in the reference, whose
+ * msm_bigint picks its window width inside ark-ec; for benchmarks and tests that account for the work of an MSM): bits per window,
+ * windows per scalar (= mixed additions per scalar on this rank), buckets. */
+int32_t plk_msm_plan_query(plk_ctx* ctx, uint64_t k, uint64_t base_offset, int32_t* window_bits, int32_t* windows, int32_t* buckets);
 
 /* ---- radix-2 NTT (ark-poly Radix2EvaluationDomain::fft / ifft; src/prover.rs:232,233,237,
  * src/circuit.rs:404,438,454,543, src/poly_utils.rs:9,27,28).  In place, natural order in and out, size 2^log_n.

@@ -322,7 +322,7 @@ extern "C" int32_t plk_destroy(plk_ctx* ctx) {
     delete static_cast<StagePool*>(ctx->stage);
     ctx->stage = nullptr;
     ntt_release(ctx);
-    hipFree(ctx->tables); hipFree(ctx->tables_short); hipFree(ctx->marg_all_dev); hipHostFree(ctx->marg_all_host); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
+    hipFree(ctx->tables); hipFree(ctx->tables_mid); hipFree(ctx->tables_short); hipFree(ctx->marg_all_dev); hipHostFree(ctx->marg_all_host); hipFree(ctx->scratch); hipFree(ctx->flag_dev); hipHostFree(ctx->flag_host);
     streams_release(ctx);
     delete ctx;
     return PLK_OK;
@@ -681,7 +681,7 @@ static void plan_units(uint32_t count, const uint64_t* share, const int* plan, L
     static const uint64_t group_entries = getenv("PLK_WIDE_GROUP_ENTRIES") ? strtoull(getenv("PLK_WIDE_GROUP_ENTRIES"), nullptr, 0) : WIDE_GROUP_ENTRIES;
     uint32_t narrow[MSM_SLOTS], nn = 0, first_narrow = count;
     uint64_t narrow_scalars = 0;
-    for (uint32_t k = 0; k < count; ++k) if (plan[k] != MSM_C) { if (!nn) first_narrow = k; narrow[nn++] = k; narrow_scalars += share[k]; }
+    for (uint32_t k = 0; k < count; ++k) if (plan[k] == MSM_C_SHORT) { if (!nn) first_narrow = k; narrow[nn++] = k; narrow_scalars += share[k]; }
     const uint32_t narrow_pos = narrow_scalars <= 4096 ? first_narrow : count;
     auto put_narrow = [&]() {
         if (!nn) return;
@@ -690,13 +690,13 @@ static void plan_units(uint32_t count, const uint64_t* share, const int* plan, L
         ++out->n;
     };
     out->n = 0;
-    int open = -1;                      // the unit that still takes wide members
+    int open = -1;                      // the unit that still takes members (of its own plan)
     uint64_t open_entries = 0;
     for (uint32_t k = 0; k < count; ++k) {
-        if (k == narrow_pos) put_narrow();   // an open wide unit goes on taking members: it was begun before the narrow group and stays in front of it
-        if (plan[k] != MSM_C) continue;
-        const uint64_t e = share[k] * (uint64_t)MsmPlan<MSM_C>::WINDOWS;
-        if (open < 0 || open_entries + e > group_entries) { open = (int)out->n++; out->plan[open] = MSM_C; out->size[open] = 0; open_entries = 0; }
+        if (k == narrow_pos) put_narrow();   // an open unit goes on taking members: it was begun before the narrow group and stays in front of it
+        if (plan[k] == MSM_C_SHORT) continue;
+        const uint64_t e = share[k] * (uint64_t)msm_plan_windows(plan[k]);
+        if (open < 0 || out->plan[open] != plan[k] || open_entries + e > group_entries) { open = (int)out->n++; out->plan[open] = plan[k]; out->size[open] = 0; open_entries = 0; }
         out->member[open][out->size[open]++] = k;
         open_entries += e;
     }

@@ -13,24 +13,26 @@
 namespace plk {
 
 // Window layouts of the MSM.  Every window has its own table of 2^(C j) * P, so all windows of an MSM share one set of 2^(C-1)
-// buckets (digit magnitude 1..2^(C-1) -> bucket 0..2^(C-1)-1).  Two widths: 16-bit windows (16 signed digits per scalar, 2^15
-// buckets) for long MSMs, 13-bit windows (20 digits, 2^12 buckets) for short ones, where the reduction of the buckets, whose cost
-// does not depend on the MSM's length, would otherwise be a fifth of the work and most of the latency.
-constexpr int MSM_C = 16, MSM_C_SHORT = 13;
+// buckets (digit magnitude 1..2^(C-1) -> bucket 0..2^(C-1)-1).  Three widths, chosen by the number of scalars an MSM has on this
+// rank: 17-bit windows (15 signed digits per scalar, 2^16 buckets) for long MSMs, where a sixteenth fewer additions outweigh the
+// doubled reduction of the buckets; 16-bit windows (16 digits, 2^15 buckets) in between; 13-bit windows (20 digits, 2^12 buckets) for
+// short ones, where the reduction, whose cost does not depend on the MSM's length, would otherwise be a fifth of the work and most
+// of the latency.  The tables of the long plan cover all points of the rank, those of the other two a prefix (a short MSM of the
+// prover starts at power 0).
+constexpr int MSM_C_LONG = 17, MSM_C = 16, MSM_C_SHORT = 13;
 template <int C>
 struct MsmPlan {
-    static constexpr int WINDOWS = (254 + C - 1) / C;                 // 16 | 20: the top window's digit is small, its carry never leaves the scalar
-    static constexpr int BUCKETS = 1 << (C - 1);                      // 32768 | 4096
-    static constexpr int DIGIT_WORDS = WINDOWS / 2;                   // two-byte digit codes per scalar, as 32-bit words
-    static constexpr int FIELDS = (C - 1 + 3) / 4;                    // bit-fields of the bucket index in the marginal sums: 4 | 3
-    static constexpr int LAST_BITS = C - 1 - 4 * (FIELDS - 1);        // width of the top field: 3 | 4 (the others have 4 bits)
-    static constexpr int MARGINALS = 16 * (FIELDS - 1) + (1 << LAST_BITS);   // 56 | 48 partial sums handed to the host
-    static_assert(WINDOWS % 2 == 0 && WINDOWS * C >= 255, "window layout");
+    static constexpr int WINDOWS = (254 + C - 1) / C;                 // 15 | 16 | 20: the top window's digit is small, its carry never leaves the scalar
+    static constexpr int BUCKETS = 1 << (C - 1);                      // 65536 | 32768 | 4096
+    static constexpr int FIELDS = (C - 1 + 3) / 4;                    // bit-fields of the bucket index in the marginal sums: 4 | 4 | 3
+    static constexpr int LAST_BITS = C - 1 - 4 * (FIELDS - 1);        // width of the top field: 4 | 3 | 4 (the others have 4 bits)
+    static constexpr int MARGINALS = 16 * (FIELDS - 1) + (1 << LAST_BITS);   // 64 | 56 | 48 partial sums handed to the host
+    static_assert(WINDOWS * C >= 255 && C >= 10 && C <= 17, "window layout");
 };
 constexpr int MSM_MAX_WINDOWS = 20;
-constexpr int MSM_BUCKETS = MsmPlan<MSM_C>::BUCKETS;   // the larger of the two bucket counts: sizes the per-slot scratch
+constexpr int MSM_BUCKETS = MsmPlan<MSM_C_LONG>::BUCKETS;   // the largest of the bucket counts: sizes the per-slot scratch
+constexpr int MSM_MARGINALS = 64;       // the largest of the plans' outputs
 constexpr int MSM_SLOTS = 10;           // MSMs in flight (a round of the prover enqueues up to nine at once)
-constexpr int MSM_MARGINALS = 56;       // the larger of the two plans' outputs
 constexpr int XYZZ_WORDS = 36;          // unnormalised point in device scratch: 4 coordinates x 9 limbs
 
 struct MsmSeg {
@@ -72,7 +74,7 @@ struct MsmSlot {
     uint32_t* tails = nullptr;         // [XYZZ_WORDS][tail_cap] what each accumulation lane held at the end of its run
     uint64_t tail_cap = 0;
     uint32_t* marg_dev = nullptr;      // [MSM_MARGINALS][32]
-    uint32_t* marg_part = nullptr;     // [16384][XYZZ_WORDS] partial marginal sums (every lane of k_msm_marginals_part stores one)
+    uint32_t* marg_part = nullptr;     // [32768][XYZZ_WORDS] partial marginal sums (every lane of k_msm_marginals_part stores one)
     uint32_t* marg_host = nullptr;     // pinned
     uint32_t* blind_dev = nullptr;     // 3 Fr (+ room for opening scalars)
     uint32_t* blind_host = nullptr;    // pinned staging
@@ -86,7 +88,7 @@ struct MsmSlot {
     int kind = 0;                      // 0 msm, 1 commit, 2 open
     uint64_t max_entries = 0;          // of the job in flight: its accumulation time is proportional to this
     int acc_stream = 0;                // which of the two accumulation streams runs it
-    int plan_c = MSM_C;                // window width of the job in flight
+    int plan_c = MSM_C_LONG;           // window width of the job in flight
     int ev_owner = 0;                  // slot whose `accumulated` event covers this job (members of a batch share their launches)
     int done_owner = 0;                // slot whose `done` event covers this job's read-back
     uint32_t acc_blocks = 0;
@@ -130,10 +132,13 @@ struct plk_ctx {
     uint32_t cyc_world = 1, cyc_rank = 0, cyc_log_block = 0;   // cyc_world > 1: block-cyclic shard (shard_first unused, shard_len = points held)
     bool has_gamma = false;
     uint64_t table_stride = 0;         // points per window table: shard_len + 3 (gamma powers at the end)
-    uint32_t* tables = nullptr;        // [16 windows][table_stride] affine, 16 words each, x*2^261 form: 2^(16 j) P
-    uint32_t* tables_short = nullptr;  // [20 windows][table_stride]: 2^(13 j) P, for the MSMs short enough for the narrow plan
+    uint32_t* tables = nullptr;        // [15 windows][table_stride] affine, 16 words each, x*2^261 form: 2^(17 j) P
+    uint32_t* tables_mid = nullptr;    // [16 windows][mid_stride]: 2^(16 j) P over a prefix, for the MSMs of middling length
+    uint64_t mid_max = 0;              // MSMs of at most this many scalars (on this rank) take the 16-bit plan (0: never)
+    uint64_t mid_len = 0, mid_stride = 0;       // points those tables cover (a prefix of this rank's points), points per table (prefix + 3 gamma powers)
+    uint32_t* tables_short = nullptr;  // [20 windows][short_stride]: 2^(13 j) P, for the MSMs short enough for the narrow plan
     uint64_t short_max = 0;            // MSMs of at most this many scalars take the narrow plan (0: never)
-    uint64_t short_len = 0, short_stride = 0;   // points the narrow tables cover (a prefix of this rank's points), points per narrow table (prefix + 3 gamma powers)
+    uint64_t short_len = 0, short_stride = 0;   // as mid_len, mid_stride
     uint32_t* marg_all_dev = nullptr;  // [MSM_SLOTS][MSM_MARGINALS][32]: the slots' outputs side by side, so that a batch of reductions is read back with one copy
     uint32_t* marg_all_host = nullptr; // pinned
     // NTT

@@ -25,7 +25,8 @@ struct MsmJob {
     uint32_t n_blind;
     const uint32_t* blind_dev;   // null: the slot's own buffer
 };
-int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset);   // MSM_C or MSM_C_SHORT
+int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset);   // MSM_C_LONG, MSM_C or MSM_C_SHORT
+int msm_plan_windows(int plan_c);
 uint64_t msm_share(const plk_ctx* ctx, uint64_t k, uint64_t base_offset);   // scalars of that range on this rank
 int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStream_t lane, int idle_hint, int plan_c);
 int32_t msm_wait(plk_ctx* ctx, MsmSlot& s, host::pt* out);

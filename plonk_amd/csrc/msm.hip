@@ -3,11 +3,12 @@
 // Layout.  The SRS is resident as tables T[j][i] = 2^(C j) * P_i, one per window j (affine, 64 B per point, coordinates in the
 // 2^261 Montgomery form of fp29.cuh).  With one table per window all windows share a single set of 2^(C-1) buckets:
 // sum_i s_i P_i = sum_k k * B_k,  B_k = sum of +-T[j][i] over all (i, j) whose signed C-bit digit has magnitude k.
-// Two plans (MsmPlan in common.cuh): C = 16 over the whole SRS, C = 13 over a prefix of it for short MSMs.
+// Three plans (MsmPlan in common.cuh): C = 17 over the whole SRS, C = 16 and C = 13 over prefixes of it for shorter MSMs.
 //
 // Pipeline of one MSM (sort on a front stream, accumulation and reduction on streams of their own, several MSMs in flight):
-//   digits + count : signed digits of every scalar as two-byte codes, histogram of 256 partitions per workgroup
-//   partition      : every workgroup appends its 8-byte records to its own piece of each partition (upper 8 bucket bits)
+//   count          : signed digits of every scalar, histogram of 256 partitions per workgroup
+//   partition      : the digits again (cheaper than keeping them: a product and some shifts against 32 bytes written and read per
+//                    scalar); every workgroup appends its 8-byte records to its own piece of each partition (upper 8 bucket bits)
 //   buckets        : one workgroup per partition spreads the records over the partition's buckets -> entries sorted by bucket
 //   accumulate: every lane adds one run of consecutive sorted entries (mixed XYZZ additions); sums of runs that end inside a
 //               bucket are joined by the fold kernel                              -> bucket_sums
@@ -59,12 +60,6 @@ __device__ __forceinline__ const uint32_t* seg_scalar(const MsmSegs& segs, uint3
 }
 
 constexpr int SORT_THREADS = 256;   // four waves per block: a block fits beside the accumulation kernel's waves on a busy CU
-// Digit of one window as a 16-bit code: bit 15 = sign, bits 0-14 = bucket (|d| - 1); 0xffff = no entry (d = 0; the code would
-// otherwise mean d = -2^15, which the signed recoding never produces).
-constexpr uint32_t DIGIT_NONE = 0xffffu;
-__device__ __forceinline__ uint32_t digit_code(int32_t d) {
-    return d == 0 ? DIGIT_NONE : ((d < 0 ? 0x8000u : 0u) | (uint32_t)((d < 0 ? -d : d) - 1));
-}
 
 // ------------------------------------------------------------------------------------------ two-level sort
 // A one-level scatter (every workgroup writes each entry straight to its bucket's slot, cursors per workgroup and bucket) hands
@@ -73,21 +68,21 @@ __device__ __forceinline__ uint32_t digit_code(int32_t d) {
 // entry bytes written, 2.35 ms per proof of 2^20 gates lost by the accumulation kernels beside it).  Here the entries first go to
 // SORT_PARTS = 256 partitions by the upper eight bits of their bucket (8-byte records: entry word + the lower bucket bits), each
 // workgroup appending to its own reserved piece of a partition, so the 256 lines it has open fill within an iteration or two; then
-// one workgroup per partition spreads its records over the partition's buckets (128 with 16-bit windows, 16 with 13-bit ones), all
-// inside a region that stays in the L2 until its lines are full.  Three launches; 1 KB of LDS per workgroup.
+// one workgroup per partition spreads its records over the partition's buckets (256, 128 or 16 by window width), all inside a
+// region that stays in the L2 until its lines are full.  Three launches; 1 KB of LDS per workgroup.
 constexpr int SORT_PARTS = 256;
 constexpr int SORT_MAX_BLOCKS = 512;                                            // workgroups of the first two kernels (rows of the count matrix)
 template <int C>
 struct SortPlan {
-    static constexpr int PART_BITS = C - 1 - 8;                                 // bucket bits below the partition: 7 | 4
-    static constexpr int PART_BUCKETS = 1 << PART_BITS;                         // buckets per partition: 128 | 16
+    static constexpr int PART_BITS = C - 1 - 8;                                 // bucket bits below the partition: 8 | 7 | 4
+    static constexpr int PART_BUCKETS = 1 << PART_BITS;                         // buckets per partition: 256 | 128 | 16
+    static_assert(PART_BUCKETS <= SORT_THREADS, "one counter per thread in k_sort_buckets");
 };
 // What the three kernels need to know about every member of a batch.
 struct SortBatch {
     MsmSegs segs[MSM_SLOTS];
     uint32_t chunk[MSM_SLOTS];         // scalars per workgroup of the first two kernels
     uint32_t nblocks[MSM_SLOTS];       // workgroups of the member (the launch has the largest count; the others leave)
-    uint32_t* digits[MSM_SLOTS];       // digit codes, DIGIT_WORDS words per scalar
     uint32_t* counts[MSM_SLOTS];       // [workgroup][SORT_PARTS]
     uint32_t* part_start[MSM_SLOTS];   // SORT_PARTS + 1 words
     uint64_t* records[MSM_SLOTS];
@@ -95,15 +90,14 @@ struct SortBatch {
     uint32_t* entries[MSM_SLOTS];
     uint32_t table_stride;
 };
-// digits of every scalar (WINDOWS two-byte codes) + this workgroup's histogram of partitions -> counts[workgroup][SORT_PARTS]
+// this workgroup's histogram of partitions -> counts[workgroup][SORT_PARTS]
 template <int C>
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(SortBatch sb) {
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_count(SortBatch sb) {
     PLK_SIDE_PRIO();
-    constexpr int W = MsmPlan<C>::WINDOWS, DW = MsmPlan<C>::DIGIT_WORDS;
+    constexpr int W = MsmPlan<C>::WINDOWS;
     const uint32_t mb = blockIdx.y;
     if (blockIdx.x >= sb.nblocks[mb]) return;
     const MsmSegs& segs = sb.segs[mb];
-    uint32_t* __restrict__ digits = sb.digits[mb];
     const uint32_t chunk = sb.chunk[mb];
     __shared__ uint32_t hist[SORT_PARTS];
     hist[threadIdx.x] = 0;
@@ -118,17 +112,9 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(SortBatch sb
         if (idx + SORT_THREADS < hi) load8(seg_scalar(segs, idx + SORT_THREADS, &ti), sw_next);   // in flight while this scalar is converted
         int32_t d[W];
         scalar_digits<C>(sw, d);
-        uint32_t w[DW];
 #pragma unroll
-        for (int j = 0; j < W; j += 2) {
-            const uint32_t c0 = digit_code(d[j]), c1 = digit_code(d[j + 1]);
-            w[j / 2] = c0 | (c1 << 16);
-            if (c0 != DIGIT_NONE) atomicAdd(&hist[(c0 & 0x7fffu) >> SortPlan<C>::PART_BITS], 1u);
-            if (c1 != DIGIT_NONE) atomicAdd(&hist[(c1 & 0x7fffu) >> SortPlan<C>::PART_BITS], 1u);
-        }
-        uint2* dst = reinterpret_cast<uint2*>(digits + (size_t)DW * idx);      // DW is even: eight-byte stores
-#pragma unroll
-        for (int i = 0; i < DW / 2; ++i) dst[i] = make_uint2(w[2 * i], w[2 * i + 1]);
+        for (int j = 0; j < W; ++j)
+            if (d[j] != 0) atomicAdd(&hist[(uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1) >> SortPlan<C>::PART_BITS], 1u);
     }
     __syncthreads();
     sb.counts[mb][(size_t)blockIdx.x * SORT_PARTS + threadIdx.x] = hist[threadIdx.x];
@@ -141,11 +127,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_digits_count(SortBatch sb
 template <int C>
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(SortBatch sb) {
     PLK_SIDE_PRIO();
-    constexpr int W = MsmPlan<C>::WINDOWS, DW = MsmPlan<C>::DIGIT_WORDS;
+    constexpr int W = MsmPlan<C>::WINDOWS;
     const uint32_t mb = blockIdx.y, nblocks = sb.nblocks[mb];
     if (blockIdx.x >= nblocks) return;
     const MsmSegs& segs = sb.segs[mb];
-    const uint32_t* __restrict__ digits = sb.digits[mb];
     const uint32_t* __restrict__ part_counts = sb.counts[mb];
     uint32_t* __restrict__ part_start = sb.part_start[mb];
     uint64_t* __restrict__ records = sb.records[mb];
@@ -183,27 +168,22 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_partition(SortBatch sb) {
     }
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, segs.total);
-    uint32_t w_next[DW];
-    auto load_codes = [&](uint32_t idx, uint32_t* w) {
-        const uint2* src = reinterpret_cast<const uint2*>(digits + (size_t)DW * idx);
-#pragma unroll
-        for (int i = 0; i < DW / 2; ++i) { const uint2 v = src[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
-    };
-    if (lo + threadIdx.x < hi) load_codes(lo + threadIdx.x, w_next);
+    uint32_t sw_next[8], ti_next = 0;
+    if (lo + threadIdx.x < hi) load8(seg_scalar(segs, lo + threadIdx.x, &ti_next), sw_next);
     for (uint32_t idx = lo + threadIdx.x; idx < hi; idx += SORT_THREADS) {
-        uint32_t ti;
-        (void)seg_scalar(segs, idx, &ti);
-        uint32_t w[DW];
+        const uint32_t ti = ti_next;
+        uint32_t sw[8];
 #pragma unroll
-        for (int i = 0; i < DW; ++i) w[i] = w_next[i];
-        if (idx + SORT_THREADS < hi) load_codes(idx + SORT_THREADS, w_next);   // in flight while these codes are placed
+        for (int i = 0; i < 8; ++i) sw[i] = sw_next[i];
+        if (idx + SORT_THREADS < hi) load8(seg_scalar(segs, idx + SORT_THREADS, &ti_next), sw_next);   // in flight while this scalar is placed
+        int32_t d[W];
+        scalar_digits<C>(sw, d);
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-            const uint32_t code = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            if (code == DIGIT_NONE) continue;
-            const uint32_t b = code & 0x7fffu;
+            if (d[j] == 0) continue;
+            const uint32_t b = (uint32_t)((d[j] < 0 ? -d[j] : d[j]) - 1);
             const uint32_t slot = atomicAdd(&cursor[b >> SortPlan<C>::PART_BITS], 1u);
-            const uint32_t entry = ((code & 0x8000u) << 16) | ((uint32_t)j * table_stride + ti);
+            const uint32_t entry = (d[j] < 0 ? 0x80000000u : 0u) | ((uint32_t)j * table_stride + ti);
             records[slot] = (uint64_t)entry | ((uint64_t)(b & (SortPlan<C>::PART_BUCKETS - 1)) << 32);
         }
     }
@@ -221,7 +201,7 @@ __global__ void __launch_bounds__(T) k_sort_buckets(SortBatch sb) {
     uint32_t* __restrict__ bucket_start = sb.bucket_start[mb];
     uint32_t* __restrict__ entries = sb.entries[mb];
     __shared__ uint32_t cnt[PB];
-    __shared__ uint32_t wave_sum[2];
+    __shared__ uint32_t wave_sum[4];
     const uint32_t p = blockIdx.x, t = threadIdx.x;
     const uint32_t first = part_start[p], last = part_start[p + 1];
     if (t < PB) cnt[t] = 0;
@@ -235,15 +215,16 @@ __global__ void __launch_bounds__(T) k_sort_buckets(SortBatch sb) {
         for (int k = 0; k < 4; ++k) if (r[k] != ~0ull) atomicAdd(&cnt[(uint32_t)(r[k] >> 32)], 1u);
     }
     __syncthreads();
-    {                                   // exclusive scan of the counters (the first two waves hold them)
+    {                                   // exclusive scan of the counters (the first four waves hold them)
         const uint32_t lane = t & 63, wave = t >> 6, c = t < PB ? cnt[t] : 0;
         uint32_t incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += x; }
-        if (lane == 63 && wave < 2) wave_sum[wave] = incl;
+        if (lane == 63 && wave < 4) wave_sum[wave] = incl;
         __syncthreads();
         if (t < PB) {
-            const uint32_t start = first + incl - c + (wave ? wave_sum[0] : 0);
+            uint32_t start = first + incl - c;
+            for (uint32_t k2 = 0; k2 < wave; ++k2) start += wave_sum[k2];
             bucket_start[p * PB + t] = start;
             cnt[t] = start;             // from here on: the next free slot of the bucket
         }
@@ -447,10 +428,10 @@ struct MargPlan {
     using P = MsmPlan<C>;
     static constexpr int NA = 16 * (P::FIELDS - 1), NB = 1 << P::LAST_BITS;                         // outputs of the 4-bit fields, of the top field
     static constexpr int PART_A = (P::BUCKETS >> 4) / MARG_K, PART_B = (P::BUCKETS >> P::LAST_BITS) / MARG_K;   // partial sums per output
-    static constexpr int PARTIALS = NA * PART_A + NB * PART_B;                                       // 16384 | 1536 per MSM
+    static constexpr int PARTIALS = NA * PART_A + NB * PART_B;                                       // 32768 | 16384 | 1536 per MSM
     static_assert(PARTIALS % 64 == 0, "whole waves");
 };
-constexpr int MARG_PARTIALS_MAX = MargPlan<MSM_C>::PARTIALS;
+constexpr int MARG_PARTIALS_MAX = MargPlan<MSM_C_LONG>::PARTIALS;
 template <int C> __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb);
 template <int C> __device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb);
 template <int C>
@@ -559,6 +540,26 @@ __global__ void __launch_bounds__(256) k_srs_generate(const uint32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ host side
+// What the host needs to know about a window plan on this context: its layout and the tables it runs on.
+struct PlanView {
+    int c, windows, buckets;
+    const uint32_t* tables;
+    uint64_t len;      // points of this rank the tables cover (a prefix; all of them for the long plan); the gamma powers follow
+    uint64_t stride;   // points per window table: len + 3
+};
+static PlanView plan_view(const plk_ctx* ctx, int plan_c) {
+    if (plan_c == MSM_C_SHORT) return {MSM_C_SHORT, MsmPlan<MSM_C_SHORT>::WINDOWS, MsmPlan<MSM_C_SHORT>::BUCKETS, ctx->tables_short, ctx->short_len, ctx->short_stride};
+    if (plan_c == MSM_C) return {MSM_C, MsmPlan<MSM_C>::WINDOWS, MsmPlan<MSM_C>::BUCKETS, ctx->tables_mid, ctx->mid_len, ctx->mid_stride};
+    return {MSM_C_LONG, MsmPlan<MSM_C_LONG>::WINDOWS, MsmPlan<MSM_C_LONG>::BUCKETS, ctx->tables, ctx->shard_len, ctx->table_stride};
+}
+int msm_plan_windows(int plan_c) { return plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::WINDOWS : plan_c == MSM_C ? MsmPlan<MSM_C>::WINDOWS : MsmPlan<MSM_C_LONG>::WINDOWS; }
+// f.template operator()<C>() for the plan's window width
+#define PLK_FOR_PLAN(plan_c, ...)                                                         \
+    do {                                                                                  \
+        if ((plan_c) == MSM_C_SHORT) { constexpr int C = MSM_C_SHORT; __VA_ARGS__; }      \
+        else if ((plan_c) == MSM_C) { constexpr int C = MSM_C; __VA_ARGS__; }             \
+        else { constexpr int C = MSM_C_LONG; __VA_ARGS__; }                               \
+    } while (0)
 static int32_t slot_init(plk_ctx* ctx, MsmSlot& s) {
     if (s.ready) return PLK_OK;
     if (!ctx->marg_all_dev) {
@@ -610,14 +611,16 @@ static int32_t tails_reserve(plk_ctx* ctx, MsmSlot& s, uint64_t lanes) {
 // Sizes the per-MSM scratch of every slot for the largest job this SRS admits, so that no allocation (an implicit device
 // synchronisation) happens while proofs are running.
 static int32_t slots_reserve(plk_ctx* ctx) {
-    const uint64_t max_scalars = ctx->shard_len + 3;
-    uint64_t entries = max_scalars * MsmPlan<MSM_C>::WINDOWS;
-    if (ctx->tables_short) entries = std::max<uint64_t>(entries, (std::min<uint64_t>(ctx->shard_len, ctx->short_len) + 3) * MsmPlan<MSM_C_SHORT>::WINDOWS);
-    entries = (entries + 1024 + 15) & ~15ull;   // a multiple of 16: the digit codes behind the entries are stored 16 bytes at a time
+    uint64_t entries = 0;
+    for (int c : {MSM_C_LONG, MSM_C, MSM_C_SHORT}) {
+        const PlanView v = plan_view(ctx, c);
+        if (v.tables) entries = std::max<uint64_t>(entries, (v.len + 3) * v.windows);
+    }
+    entries = (entries + 1024 + 15) & ~15ull;
     const uint64_t scal_words = (ctx->srs_total + 1) * 8, chain_words = division_work_words(ctx->srs_total);
     for (auto& s : ctx->slot) {
         PLK_TRY(slot_init(ctx, s));
-        if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 14)); s.entries_cap = entries; }   // per entry: 4 bytes sorted entry + 2 digit code + 8 record of the two-level sort
+        if (s.entries_cap < entries) { if (s.entries) PLK_HIP(hipFree(s.entries)); s.entries = nullptr; s.entries_cap = 0; PLK_HIP(hipMalloc(&s.entries, entries * 12)); s.entries_cap = entries; }   // per entry: 4 bytes sorted entry + 8 record of the two-level sort
         PLK_TRY(tails_reserve(ctx, s, acc_lanes(entries, 16)));
         if (s.scal_cap < scal_words) { if (s.scal_dev) PLK_HIP(hipFree(s.scal_dev)); s.scal_dev = nullptr; s.scal_cap = 0; PLK_HIP(hipMalloc(&s.scal_dev, scal_words * 4)); s.scal_cap = scal_words; }
         if (s.chain_cap < chain_words) { if (s.chain_dev) PLK_HIP(hipFree(s.chain_dev)); s.chain_dev = nullptr; s.chain_cap = 0; PLK_HIP(hipMalloc(&s.chain_dev, chain_words * 4)); s.chain_cap = chain_words; }
@@ -679,13 +682,16 @@ uint64_t msm_share(const plk_ctx* ctx, uint64_t k, uint64_t base_offset) {
     clip_to_shard(ctx, nullptr, k, base_offset, &seg);
     return seg.count;
 }
-// Window width for the MSM over the global range [base_offset, base_offset + k): the narrow plan when this rank's share is short
-// and lies inside the prefix of the SRS that the narrow tables cover.
+// Window width for the MSM over the global range [base_offset, base_offset + k): by the number of scalars on this rank; the two
+// narrower plans only when the range lies inside the prefix of the SRS that their tables cover.
 int msm_plan_for(const plk_ctx* ctx, uint64_t k, uint64_t base_offset) {
-    if (!ctx->tables_short || base_offset + k > ctx->srs_total) return MSM_C;
+    if (base_offset + k > ctx->srs_total) return MSM_C_LONG;
     MsmSeg seg;
     clip_to_shard(ctx, nullptr, k, base_offset, &seg);
-    return (seg.count <= ctx->short_max && (uint64_t)seg.table_off + seg.count <= ctx->short_len) ? MSM_C_SHORT : MSM_C;
+    const uint64_t end = (uint64_t)seg.table_off + seg.count;
+    if (ctx->tables_short && seg.count <= ctx->short_max && end <= ctx->short_len) return MSM_C_SHORT;
+    if (ctx->tables_mid && seg.count <= ctx->mid_max && end <= ctx->mid_len) return MSM_C;
+    return MSM_C_LONG;
 }
 
 // The stream for the front work (division, sort) of the next job: consecutive jobs alternate between the compute stream and the
@@ -699,7 +705,7 @@ hipStream_t front_lane(plk_ctx* ctx) {
 
 template <int C>
 static void launch_sort(hipStream_t st, const SortBatch& sb, uint32_t max_blocks, uint32_t n, bool fast) {
-    hipLaunchKernelGGL(k_sort_digits_count<C>, dim3(max_blocks, n), dim3(SORT_THREADS), 0, st, sb);
+    hipLaunchKernelGGL(k_sort_count<C>, dim3(max_blocks, n), dim3(SORT_THREADS), 0, st, sb);
     hipLaunchKernelGGL(k_sort_partition<C>, dim3(max_blocks, n), dim3(SORT_THREADS), 0, st, sb);
     if (fast) hipLaunchKernelGGL((k_sort_buckets<1024, C>), dim3(SORT_PARTS, n), dim3(1024), 0, st, sb);
     else hipLaunchKernelGGL((k_sort_buckets<SORT_THREADS, C>), dim3(SORT_PARTS, n), dim3(SORT_THREADS), 0, st, sb);
@@ -710,10 +716,9 @@ static void launch_sort(hipStream_t st, const SortBatch& sb, uint32_t max_blocks
 int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStream_t lane, int idle_hint, int plan_c) {
     if (!ctx->tables) { ctx->err = "no SRS loaded"; return PLK_ERR_INVALID_ARG; }
     if (n == 0 || n > (uint32_t)MSM_SLOTS) return PLK_ERR_INVALID_ARG;
-    const bool narrow = plan_c == MSM_C_SHORT;
-    if (narrow && !ctx->tables_short) { ctx->err = "narrow window plan without its tables"; return PLK_ERR_INVALID_ARG; }
-    const uint32_t windows = narrow ? MsmPlan<MSM_C_SHORT>::WINDOWS : MsmPlan<MSM_C>::WINDOWS;
-    const uint32_t buckets = narrow ? MsmPlan<MSM_C_SHORT>::BUCKETS : MsmPlan<MSM_C>::BUCKETS;
+    const PlanView plan = plan_view(ctx, plan_c);
+    if (!plan.tables) { ctx->err = "window plan without its tables"; return PLK_ERR_INVALID_ARG; }
+    const uint32_t windows = (uint32_t)plan.windows;
     hipStream_t st = lane ? lane : ctx->st_sort;
     bool idle = ctx->reduce_pending.empty();   // nothing of this context is running or queued on the device
     for (const auto& other : ctx->slot) {
@@ -724,7 +729,7 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
     if (idle_hint >= 0) idle = idle_hint != 0;   // a batch marks all its slots busy before it enqueues the first
     SortBatch sb;
     memset(&sb, 0, sizeof(sb));
-    sb.table_stride = (uint32_t)(narrow ? ctx->short_stride : ctx->table_stride);
+    sb.table_stride = (uint32_t)plan.stride;
     uint64_t max_entries[MSM_SLOTS], total_entries = 0;
     uint32_t max_blocks = 1;
     // Raised issue priority for every sort: given to the first four sorts of a round only, the later ones take twice as long, the
@@ -743,10 +748,10 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
         if (j.base_offset + j.k > ctx->srs_total) { ctx->err = "MSM longer than the SRS"; return PLK_ERR_SRS_TOO_SHORT; }
         MsmSegs& segs = sb.segs[m];
         clip_to_shard(ctx, j.scalars, j.k, j.base_offset, &segs.s[0]);
-        if (narrow && ((uint64_t)segs.s[0].table_off + segs.s[0].count > ctx->short_len)) { ctx->err = "MSM outside the prefix of the narrow tables"; return PLK_ERR_INVALID_ARG; }
+        if ((uint64_t)segs.s[0].table_off + segs.s[0].count > plan.len) { ctx->err = "MSM outside the prefix that the plan's tables cover"; return PLK_ERR_INVALID_ARG; }
         segs.s[1].scalars = j.blind_dev ? j.blind_dev : s.blind_dev;
         segs.s[1].count = ctx->has_gamma ? j.n_blind : 0;
-        segs.s[1].table_off = (uint32_t)(narrow ? ctx->short_len : ctx->shard_len);
+        segs.s[1].table_off = (uint32_t)plan.len;
         segs.s[1].world = 1; segs.s[1].rank = 0; segs.s[1].log_block = 0; segs.s[1].origin = 0;
         segs.nseg = 2;
         segs.total = segs.s[0].count + segs.s[1].count;
@@ -755,8 +760,8 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
         if (max_entries[m] > s.entries_cap) {   // the slot is idle here: its previous job was waited for before it was handed out again
             if (s.entries) PLK_HIP(hipFree(s.entries));
             s.entries = nullptr; s.entries_cap = 0;
-            const uint64_t cap = (max_entries[m] + max_entries[m] / 8 + 1024 + 15) & ~15ull;   // the digit codes behind the entries are stored 16 bytes at a time
-            PLK_HIP(hipMalloc(&s.entries, cap * 14));   // 4 bytes per entry + 2 per digit code + 8 per record
+            const uint64_t cap = (max_entries[m] + max_entries[m] / 8 + 1024 + 15) & ~15ull;
+            PLK_HIP(hipMalloc(&s.entries, cap * 12));   // 4 bytes per entry + 8 per record
             s.entries_cap = cap;
         }
         uint32_t per = fast ? 2048 : 8192;
@@ -766,8 +771,7 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
         if (nb > (uint32_t)SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
         sb.nblocks[m] = nb;
         sb.chunk[m] = (segs.total + nb - 1) / nb;
-        sb.digits[m] = s.entries + s.entries_cap;      // two-byte codes, at most entries_cap of them
-        sb.records[m] = reinterpret_cast<uint64_t*>(s.entries + s.entries_cap + s.entries_cap / 2);
+        sb.records[m] = reinterpret_cast<uint64_t*>(s.entries + s.entries_cap);
         sb.counts[m] = s.counts;
         sb.part_start[m] = s.totals;                   // SORT_PARTS + 1 words (the buffer holds MSM_BUCKETS)
         sb.bucket_start[m] = s.bucket_start;
@@ -776,7 +780,7 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
     }
     // run length of the accumulation from the whole group: together the members should fill the chip a whole number of times
     uint32_t run = acc_run(total_entries);
-    if (narrow) { static const uint32_t min_run = getenv("PLK_NARROW_MIN_RUN") ? (uint32_t)atoi(getenv("PLK_NARROW_MIN_RUN")) : 16; run = std::max(run, min_run); }
+    if (plan_c == MSM_C_SHORT) { static const uint32_t min_run = getenv("PLK_NARROW_MIN_RUN") ? (uint32_t)atoi(getenv("PLK_NARROW_MIN_RUN")) : 16; run = std::max(run, min_run); }
     AccBatch ab;
     memset(&ab, 0, sizeof(ab));
     ab.n = n;
@@ -795,8 +799,7 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
     for (uint32_t m = n; m <= (uint32_t)MSM_SLOTS; ++m) ab.block_first[m] = blocks_so_far;
     MsmSlot& leader = ctx->slot[jobs[0].slot];
     prof_begin(ctx, st, "msm_sort");
-    if (narrow) launch_sort<MSM_C_SHORT>(st, sb, max_blocks, n, fast);
-    else launch_sort<MSM_C>(st, sb, max_blocks, n, fast);
+    PLK_FOR_PLAN(plan_c, launch_sort<C>(st, sb, max_blocks, n, fast));
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(leader.sorted, st));
     PLK_TRY(lane_read_mark(ctx, st, leader.sorted));   // behind the last reader of the callers' scalars (and of the division in front of the sort)
@@ -808,12 +811,9 @@ int32_t msm_enqueue_group(plk_ctx* ctx, const MsmJob* jobs, uint32_t n, hipStrea
     st = ctx->st_acc[acc_stream];
     PLK_HIP(hipStreamWaitEvent(st, leader.sorted, 0));
     prof_begin(ctx, st, "msm_accumulate");
-    const uint32_t* tables = narrow ? ctx->tables_short : ctx->tables;
-    if (narrow) hipLaunchKernelGGL(k_msm_accumulate<MsmPlan<MSM_C_SHORT>::BUCKETS>, dim3(blocks_so_far), dim3(ACC_THREADS), 0, st, ab, tables);
-    else hipLaunchKernelGGL(k_msm_accumulate<MsmPlan<MSM_C>::BUCKETS>, dim3(blocks_so_far), dim3(ACC_THREADS), 0, st, ab, tables);
+    PLK_FOR_PLAN(plan_c, hipLaunchKernelGGL(k_msm_accumulate<MsmPlan<C>::BUCKETS>, dim3(blocks_so_far), dim3(ACC_THREADS), 0, st, ab, plan.tables));
     prof_end(ctx, st);
     PLK_HIP(hipEventRecord(leader.accumulated, st));
-    (void)buckets;
     for (uint32_t m = 0; m < n; ++m) {
         MsmSlot& s = ctx->slot[jobs[m].slot];
         s.max_entries = max_entries[m];
@@ -864,7 +864,7 @@ static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group, bo
     memset(&rb, 0, sizeof(rb));
     rb.n = (int32_t)group.size();
     const int plan_c = ctx->slot[group[0]].plan_c;
-    const uint64_t buckets = plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::BUCKETS : MsmPlan<MSM_C>::BUCKETS;
+    const uint64_t buckets = (uint64_t)plan_view(ctx, plan_c).buckets;
     uint64_t tails_per_bucket = 0;
     int waited = -1, lo = MSM_SLOTS, hi = -1;
     for (int i = 0; i < rb.n; ++i) {
@@ -877,8 +877,7 @@ static int32_t enqueue_reduction(plk_ctx* ctx, const std::vector<int>& group, bo
         lo = std::min(lo, group[i]); hi = std::max(hi, group[i]);
     }
     prof_begin(ctx, st, "msm_reduce");
-    if (plan_c == MSM_C_SHORT) launch_reduction<MSM_C_SHORT>(st, rb, tails_per_bucket, tail);
-    else launch_reduction<MSM_C>(st, rb, tails_per_bucket, tail);
+    PLK_FOR_PLAN(plan_c, launch_reduction<C>(st, rb, tails_per_bucket, tail));
     prof_end(ctx, st);
     PLK_HIP(hipGetLastError());
     // One copy brings back the outputs of the whole launch: the slots' output arrays lie side by side.  Slots between the first and
@@ -967,8 +966,8 @@ int32_t msm_flush_reductions(plk_ctx* ctx) {
 // In pieces, so that several host threads can share one tail: piece 0 = the sum of all buckets (the "+1": every bucket has exactly
 // one value in field 0), piece 1 + d = sum_v v M(d, v) of field d by running sums; msm_tail_combine puts them together.
 constexpr int TAIL_PIECES = 1 + 4;
-static int plan_fields(int plan_c) { return plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::FIELDS : MsmPlan<MSM_C>::FIELDS; }
-static int plan_last_bits(int plan_c) { return plan_c == MSM_C_SHORT ? MsmPlan<MSM_C_SHORT>::LAST_BITS : MsmPlan<MSM_C>::LAST_BITS; }
+static int plan_fields(int plan_c) { int f; PLK_FOR_PLAN(plan_c, f = MsmPlan<C>::FIELDS); return f; }
+static int plan_last_bits(int plan_c) { int b; PLK_FOR_PLAN(plan_c, b = MsmPlan<C>::LAST_BITS); return b; }
 void msm_tail_piece(const uint32_t* marg, int plan_c, int piece, host::pt* out) {
     using namespace host;
     const uint64_t* m = reinterpret_cast<const uint64_t*>(marg);
@@ -1015,12 +1014,13 @@ static int32_t srs_alloc(plk_ctx* ctx, uint64_t shard_first, uint64_t shard_len,
     if (shard_first + shard_len > total_len || shard_len == 0 || shard_len + 3 >= (1ull << 27)) { ctx->err = "bad SRS shard"; return PLK_ERR_INVALID_ARG; }
     if (ctx->tables) { PLK_HIP(hipDeviceSynchronize()); PLK_HIP(hipFree(ctx->tables)); ctx->tables = nullptr; }
     if (ctx->tables_short) { PLK_HIP(hipFree(ctx->tables_short)); ctx->tables_short = nullptr; }
-    ctx->short_len = 0; ctx->short_stride = 0;
+    if (ctx->tables_mid) { PLK_HIP(hipFree(ctx->tables_mid)); ctx->tables_mid = nullptr; }
+    ctx->short_len = 0; ctx->short_stride = 0; ctx->mid_len = 0; ctx->mid_stride = 0;
     ctx->srs_total = total_len; ctx->shard_first = shard_first; ctx->shard_len = shard_len;
     ctx->cyc_world = 1; ctx->cyc_rank = 0; ctx->cyc_log_block = 0;
     ctx->has_gamma = shard_first == 0;
     ctx->table_stride = shard_len + 3;
-    PLK_HIP(hipMalloc(&ctx->tables, (size_t)MsmPlan<MSM_C>::WINDOWS * ctx->table_stride * 64));
+    PLK_HIP(hipMalloc(&ctx->tables, (size_t)MsmPlan<MSM_C_LONG>::WINDOWS * ctx->table_stride * 64));
     if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(ctx->tables + 16 * shard_len, 0, 3 * 64, ctx->stream));
     return PLK_OK;
 }
@@ -1041,39 +1041,51 @@ static int32_t srs_alloc_cyclic(plk_ctx* ctx, uint32_t rank, uint32_t world, uin
 // MSMs of at most this many scalars (on this rank) take the 13-bit plan.  Chosen where the narrow plan stops paying: it adds a
 // quarter to the additions of the accumulation and takes seven eighths off the reduction of the buckets.  Measured: a proof of 2^16
 // gates (MSMs of 2^16 scalars) 4.02-4.04 ms against 4.14-4.2 ms with 16-bit windows throughout; one rank of eight at 2^20 gates
-// (MSMs of 2^17 scalars) 7.3 against 6.8 ms.  PLK_MSM_SHORT_MAX overrides it (0: every MSM on 16-bit windows).
+// (MSMs of 2^17 scalars) 7.3 against 6.8 ms.  PLK_MSM_SHORT_MAX overrides it (0: no MSM on 13-bit windows).
 static uint64_t short_max_setting() {
     const char* e = getenv("PLK_MSM_SHORT_MAX");
     if (e && *e) return strtoull(e, nullptr, 0);
     return (1ull << 16) + 4096;
 }
-static int32_t srs_build_tables(plk_ctx* ctx) {
-    const uint64_t cnt = ctx->has_gamma ? ctx->shard_len + 3 : ctx->shard_len;   // a cyclic shard of a short SRS may hold no point at all
-    for (int j = 1; j < MsmPlan<MSM_C>::WINDOWS && cnt > 0; ++j) {
-        const uint32_t* prev = ctx->tables + (size_t)(j - 1) * ctx->table_stride * 16;
-        uint32_t* next = ctx->tables + (size_t)j * ctx->table_stride * 16;
-        hipLaunchKernelGGL(k_table_next, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, cnt, MSM_C);
+// MSMs of at most this many scalars (and more than the above) take the 16-bit plan, longer ones the 17-bit plan.
+// PLK_MSM_MID_MAX overrides it (0: no MSM on 16-bit windows).
+static uint64_t mid_max_setting() {
+    const char* e = getenv("PLK_MSM_MID_MAX");
+    if (e && *e) return strtoull(e, nullptr, 0);
+    return (1ull << 19) + 8192;
+}
+// Tables of a narrower plan over a prefix of this rank's points (every MSM of the prover starts at power 0, so a short MSM lies in
+// the prefix) and the gamma powers: windows x (prefix + 3) points.
+static int32_t build_prefix_tables(plk_ctx* ctx, int c, int windows, uint64_t max_share, uint32_t** tables, uint64_t* len, uint64_t* stride) {
+    *len = std::min<uint64_t>(ctx->shard_len, max_share);
+    *stride = *len + 3;
+    PLK_HIP(hipMalloc(tables, (size_t)windows * *stride * 64));
+    PLK_HIP(hipMemcpyAsync(*tables, ctx->tables, *len * 64, hipMemcpyDeviceToDevice, ctx->stream));
+    PLK_HIP(hipMemcpyAsync(*tables + 16 * *len, ctx->tables + 16 * ctx->shard_len, 3 * 64, hipMemcpyDeviceToDevice, ctx->stream));   // zeros on the ranks without gamma powers
+    const uint64_t cnt = ctx->has_gamma ? *stride : *len;
+    for (int j = 1; j < windows; ++j) {
+        const uint32_t* prev = *tables + (size_t)(j - 1) * *stride * 16;
+        uint32_t* next = *tables + (size_t)j * *stride * 16;
+        hipLaunchKernelGGL(k_table_next, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, cnt, c);
+        if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(next + 16 * *len, 0, 3 * 64, ctx->stream));
     }
     PLK_HIP(hipGetLastError());
-    // Tables of the narrow plan over a prefix of this rank's points (every MSM of the prover starts at power 0, so a short MSM lies in
-    // the prefix) and the gamma powers: 20 windows x (prefix + 3) points, 170 MB at most.
-    ctx->short_max = short_max_setting();
-    if (ctx->short_max > 0 && ctx->shard_len > 0) {
-        ctx->short_len = std::min<uint64_t>(ctx->shard_len, ctx->short_max);
-        ctx->short_stride = ctx->short_len + 3;
-        constexpr int W = MsmPlan<MSM_C_SHORT>::WINDOWS;
-        PLK_HIP(hipMalloc(&ctx->tables_short, (size_t)W * ctx->short_stride * 64));
-        PLK_HIP(hipMemcpyAsync(ctx->tables_short, ctx->tables, ctx->short_len * 64, hipMemcpyDeviceToDevice, ctx->stream));
-        PLK_HIP(hipMemcpyAsync(ctx->tables_short + 16 * ctx->short_len, ctx->tables + 16 * ctx->shard_len, 3 * 64, hipMemcpyDeviceToDevice, ctx->stream));   // zeros on the ranks without gamma powers
-        const uint64_t scnt = ctx->has_gamma ? ctx->short_stride : ctx->short_len;
-        for (int j = 1; j < W; ++j) {
-            const uint32_t* prev = ctx->tables_short + (size_t)(j - 1) * ctx->short_stride * 16;
-            uint32_t* next = ctx->tables_short + (size_t)j * ctx->short_stride * 16;
-            hipLaunchKernelGGL(k_table_next, dim3((unsigned)((scnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, scnt, MSM_C_SHORT);
-            if (!ctx->has_gamma) PLK_HIP(hipMemsetAsync(next + 16 * ctx->short_len, 0, 3 * 64, ctx->stream));
-        }
-        PLK_HIP(hipGetLastError());
+    return PLK_OK;
+}
+static int32_t srs_build_tables(plk_ctx* ctx) {
+    const uint64_t cnt = ctx->has_gamma ? ctx->shard_len + 3 : ctx->shard_len;   // a cyclic shard of a short SRS may hold no point at all
+    for (int j = 1; j < MsmPlan<MSM_C_LONG>::WINDOWS && cnt > 0; ++j) {
+        const uint32_t* prev = ctx->tables + (size_t)(j - 1) * ctx->table_stride * 16;
+        uint32_t* next = ctx->tables + (size_t)j * ctx->table_stride * 16;
+        hipLaunchKernelGGL(k_table_next, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, prev, next, cnt, MSM_C_LONG);
     }
+    PLK_HIP(hipGetLastError());
+    ctx->short_max = short_max_setting();
+    ctx->mid_max = mid_max_setting();
+    if (ctx->short_max > 0 && ctx->shard_len > 0)
+        PLK_TRY(build_prefix_tables(ctx, MSM_C_SHORT, MsmPlan<MSM_C_SHORT>::WINDOWS, ctx->short_max, &ctx->tables_short, &ctx->short_len, &ctx->short_stride));
+    if (ctx->mid_max > ctx->short_max && ctx->shard_len > ctx->short_len)   // no point of this rank beyond the narrow prefix: nothing for the 16-bit plan to do
+        PLK_TRY(build_prefix_tables(ctx, MSM_C, MsmPlan<MSM_C>::WINDOWS, ctx->mid_max, &ctx->tables_mid, &ctx->mid_len, &ctx->mid_stride));
     PLK_HIP(hipStreamSynchronize(ctx->stream));
     return slots_reserve(ctx);
 }
@@ -1286,6 +1298,12 @@ extern "C" int32_t plk_msm_partial_dev(plk_ctx* ctx, const void* scalars_dev, ui
     PLK_TRY(rc);
     prof_collect(ctx, false);
     host::pt_store(total, out_xyzz);
+    return PLK_OK;
+}
+extern "C" int32_t plk_msm_plan_query(plk_ctx* ctx, uint64_t k, uint64_t base_offset, int32_t* window_bits, int32_t* windows, int32_t* buckets) {
+    if (!ctx || !ctx->tables || !window_bits || !windows || !buckets) return PLK_ERR_INVALID_ARG;
+    const PlanView v = plan_view(ctx, msm_plan_for(ctx, k, base_offset));
+    *window_bits = v.c; *windows = v.windows; *buckets = v.buckets;
     return PLK_OK;
 }
 extern "C" int32_t plk_g1_sum_partials(const uint64_t* xyzz, uint64_t count, uint64_t out_xy[8], int32_t* out_is_inf) {

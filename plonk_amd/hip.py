@@ -23,7 +23,7 @@ STATUS = {
 EXPORTS = [
     "plk_create", "plk_destroy", "plk_last_error", "plk_malloc", "plk_free", "plk_upload", "plk_upload_enqueue", "plk_host_malloc", "plk_host_free", "plk_download", "plk_sync", "plk_copy_dev",
     "plk_srs_load", "plk_srs_load_shard", "plk_srs_generate", "plk_srs_generate_shard", "plk_srs_generate_cyclic", "plk_srs_load_cyclic", "plk_srs_setup", "plk_srs_setup_cyclic", "plk_srs_read",
-    "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
+    "plk_msm", "plk_msm_dev", "plk_msm_partial_dev", "plk_g1_sum_partials", "plk_msm_plan_query", "plk_ntt", "plk_ntt_dev", "plk_ntt_dev_enqueue",
     "plk_scale_powers_dev", "plk_ntt_cross_dev", "plk_ntt_sharded_dev",
     "plk_interpolate_selector", "plk_interpolate_permutation", "plk_interpolate_permutation_dev",
     "plk_grand_product", "plk_grand_product_dev", "plk_grand_product_values_dev", "plk_grand_product_dev_enqueue", "plk_quotient", "plk_quotient_dev", "plk_quotient_pi", "plk_quotient_pi_dev", "plk_quotient_dev_enqueue", "plk_quotient_dev_finish", "plk_quotient_coset", "plk_quotient_coset_dev", "plk_poly_eval", "plk_poly_eval_dev", "plk_poly_eval_dev_static",
@@ -235,6 +235,14 @@ class Context:
         out = np.empty(16, dtype=np.uint64)
         self._ck(self.lib.plk_msm_partial_dev(self.h, _vp(d_scalars), C.c_uint64(k), C.c_uint64(base_offset), _ptr(out)))
         return out
+
+    def msm_plan(self, k, base_offset=0):
+        """(bits per window, windows per scalar, buckets) of the MSM over [base_offset, base_offset + k) on this context"""
+        c, w, b = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        if os.environ.get("PLK_LIB_DIR") and not hasattr(self.lib, "plk_msm_plan_query"):
+            return 16, 16, 1 << 15     # an experiment directory with a build from before the query existed (16-bit windows throughout then)
+        self._ck(self.lib.plk_msm_plan_query(self.h, C.c_uint64(k), C.c_uint64(base_offset), C.byref(c), C.byref(w), C.byref(b)))
+        return c.value, w.value, b.value
 
     def sum_partials(self, parts):
         p = _fr(parts, (-1, 16))

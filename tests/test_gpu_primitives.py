@@ -313,27 +313,31 @@ def test_kzg_commit_open(ctx, orc, srs, length):
     assert np.array_equal(ev, want_ev)
 
 
-@pytest.mark.parametrize("short_max", ["0", "1000000"])
-def test_msm_edge_cases_on_both_window_plans(orc, monkeypatch, short_max):
-    """The library has two window plans: 16-bit windows (2^15 buckets) and, for MSMs of at most PLK_MSM_SHORT_MAX scalars, 13-bit
-    windows (2^12 buckets, 20 digits per scalar).  The setting is read when the SRS tables are built, so each plan can be forced
-    for a whole context: 0 puts every MSM on the wide plan, a large value puts every MSM of this test on the narrow one.  Both must
-    agree with the oracle on the scalars that exercise the recoding (0, 1, r - 1, digits 2^12, 2^12 + 1, 2^15, 2^15 + 1, all-ones
-    windows), on repeated bases (doubling and cancellation branches), on ragged lengths, and on hiding commitments / openings
-    begun singly and as batches."""
+@pytest.mark.parametrize("short_max,mid_max,bits", [("0", "0", 17), ("0", "1000000", 16), ("1000000", "0", 13)])
+def test_msm_edge_cases_on_every_window_plan(orc, monkeypatch, short_max, mid_max, bits):
+    """The library has three window plans: 17-bit windows (2^16 buckets, 15 digits per scalar), 16-bit windows (2^15 buckets, 16
+    digits) for MSMs of at most PLK_MSM_MID_MAX scalars and 13-bit windows (2^12 buckets, 20 digits) for MSMs of at most
+    PLK_MSM_SHORT_MAX scalars.  The settings are read when the SRS tables are built, so each plan can be forced for a whole
+    context.  All must agree with the oracle on the scalars that exercise the recoding (0, 1, r - 1, digits 2^(C-1), 2^(C-1) + 1,
+    all-ones windows, carries through every window), on repeated bases (doubling and cancellation branches), on ragged lengths,
+    and on hiding commitments / openings begun singly and as batches."""
     from plonk_amd.hip import Context
     monkeypatch.setenv("PLK_MSM_SHORT_MAX", short_max)
+    monkeypatch.setenv("PLK_MSM_MID_MAX", mid_max)
     c = Context(0)
     n = 5000
     tau = orc.fr_from_ints([TAU])[0]; gs = orc.fr_from_ints([GSCAL])[0]
     c.srs_generate(tau, gs, n + 1)
+    assert c.msm_plan(n) == (bits, -(-254 // bits), 1 << (bits - 1)) and c.msm_plan(1, base_offset=n) == c.msm_plan(n)
     one = orc.fr_from_ints([1])[0]
     g = orc.srs_powers(tau, one, 0, n + 1); gg = orc.srs_powers(tau, gs, 0, 3)
     assert np.array_equal(c.srs_read(0, 0, n + 1), g) and np.array_equal(c.srs_read(1, 0, 3), gg)
     r = pm.R_MOD
     edge = [0, 1, 2, r - 1, r - 2, (1 << 12), (1 << 12) + 1, (1 << 12) - 1, (1 << 13) - 1, 1 << 13, (1 << 15), (1 << 15) + 1, (1 << 16) - 1, 1 << 16,
             (1 << 253) + 5, int("1" * 254, 2) % r, sum(1 << (13 * j + 12) for j in range(19)), sum(1 << (16 * j + 15) for j in range(15)),
-            sum(((1 << 12) + 1) << (13 * j) for j in range(19)) % r, sum(((1 << 15) + 1) << (16 * j) for j in range(15)) % r]
+            sum(((1 << 12) + 1) << (13 * j) for j in range(19)) % r, sum(((1 << 15) + 1) << (16 * j) for j in range(15)) % r,
+            1 << 17, (1 << 17) - 1, (1 << 16) + 1, sum(1 << (17 * j + 16) for j in range(14)), sum(((1 << 16) + 1) << (17 * j) for j in range(14)) % r,
+            sum(((1 << 17) - 1) << (17 * j) for j in range(14)), (((1 << 16) - 1) << 238) % r, r - (1 << 16), r - (1 << 16) - 1]
     sc = orc.fr_from_ints(edge)
     for k in (len(edge), 1, 5):
         for off in (0, 7, n - len(edge)):

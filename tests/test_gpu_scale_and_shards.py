@@ -246,10 +246,14 @@ def test_msm_lengths_around_the_plan_boundaries(orc):
     ctx.close()
 
 
-def test_structured_scalars_through_the_trapdoor(orc):
+@pytest.mark.parametrize("short_max,mid_max", [("0", "0"), ("0", "1000000"), ("1000000", "0")])
+def test_structured_scalars_through_the_trapdoor(orc, monkeypatch, short_max, mid_max):
     """Scalars a real proof can produce and a uniform sample never does: all equal (every entry of a window lands in one bucket),
-    all zero, +-1, small values, a single non-zero coefficient, the largest digits."""
+    all zero, +-1, small values, a single non-zero coefficient, the largest digits; on each of the three window plans (17-, 16-
+    and 13-bit windows, forced through the environment for the whole context)."""
     from plonk_amd.hip import Context
+    monkeypatch.setenv("PLK_MSM_SHORT_MAX", short_max)
+    monkeypatch.setenv("PLK_MSM_MID_MAX", mid_max)
     tau_int, gs_int = 0x1F2E3D4C5B6A79880123456789ABCDEF, 0x0A1B2C3D
     n = 1 << 16
     r = pm.R_MOD
@@ -264,7 +268,9 @@ def test_structured_scalars_through_the_trapdoor(orc):
         "plus and minus one": [1 if i % 3 else r - 1 for i in range(n)],
         "small": [i % 97 for i in range(n)],
         "single coefficient": [0] * (n - 1) + [one_value],
-        "extreme digits": [int(("8000", "8001", "7fff", "ffff")[i & 3] * 15, 16) for i in range(n)],   # +2^15, -(2^15 - 1), carries through every window
+        "extreme digits": [int(("8000", "8001", "7fff", "ffff")[i & 3] * 15, 16) for i in range(n)],   # +2^15, -(2^15 - 1), carries through every 16-bit window
+        "extreme digits, 17 bits": [sum(((1 << 16), (1 << 16) + 1, (1 << 16) - 1, (1 << 17) - 1)[i & 3] << (17 * j) for j in range(14)) for i in range(n)],
+        "extreme digits, 13 bits": [sum(((1 << 12), (1 << 12) + 1, (1 << 12) - 1, (1 << 13) - 1)[i & 3] << (13 * j) for j in range(19)) for i in range(n)],
         "two buckets": [0x00010001 * (1 + (i & 1)) for i in range(n)],
     }
     for name, vals in cases.items():

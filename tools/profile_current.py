@@ -33,10 +33,11 @@ for path, ctr in ((fetch_txt, "FETCH_SIZE"), (write_txt, "WRITE_SIZE")):
         bytes_total += vals[ctr][0] * 1e3 * vals[ctr][1]
 bench = json.load(open(bench_json))
 log_n = bench["config"]["log_gates"]
-entries_total = (proofs * bench["config"]["msm_pairs_per_proof"] + iso * ((1 << log_n) + 3)) * 16
-wide = counters(sq_txt, k + "<32768>")
+iso_windows = bench["roofline"]["isolated"]["windows"]
+entries_total = proofs * bench["config"]["msm_additions_per_proof"] + iso * ((1 << log_n) + 3) * iso_windows
+wide = counters(sq_txt, k + "<%d>" % (1 << (254 // iso_windows + (1 if 254 % iso_windows else 0) - 1)))
 sq = {c: v[0] for c, v in next(iter(wide.values())).items()}
-additions_sq = (1 << 20) * 16
+additions_sq = (1 << 20) * iso_windows      # the standalone launch of the counter pass: 2^20 scalars
 out = {
     "tag": tag,
     "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
