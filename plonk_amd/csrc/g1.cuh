@@ -60,16 +60,16 @@ PLK_HD xyzz xyzz_dbl(const xyzz& p) {
     return r;
 }
 
-// acc += (q.x, q.y)   (8M + 2S on the common path)
+// acc += (q.x, q.y)   (8M + 2S).  The general formula is evaluated whatever the operands are, and the two cases it does not cover
+// (acc is the identity; acc and q have the same x) replace its result afterwards, in a branch that is almost never taken.  With the
+// cases tested first and the general formula in the last arm of the branch, the compiler joined the arms with a register copy per
+// limb of the result on the common path (38 moves per addition in the accumulation kernel's loop).
 PLK_HD void xyzz_madd(xyzz& a, const aff& q) {
-    if (xyzz_is_inf(a)) { a = xyzz_from_affine(q); norm(a.y); return; }   // q.y may be the unnormalized 2p - y
+    const bool was_inf = xyzz_is_inf(a);
     fe u2 = mul<FqP>(q.x, a.zz), s2 = mul<FqP>(q.y, a.zzz);
     fe p = sub8<FqP>(u2, a.x); norm(p);           // bound 10
     fe r = sub4<FqP>(s2, a.y); norm(r);           // bound 6
-    if (is_zero_mod<FqP>(p)) {
-        if (is_zero_mod<FqP>(r)) { aff qq = q; norm(qq.y); a = xyzz_dbl_affine(qq); } else a = xyzz_inf();
-        return;
-    }
+    const bool same_x = is_zero_mod<FqP>(p);
     fe pp = sqr<FqP>(p), ppp = mul<FqP>(p, pp), qv = mul<FqP>(a.x, pp), rr = sqr<FqP>(r);
     fe x3;
 #pragma unroll
@@ -80,6 +80,15 @@ PLK_HD void xyzz_madd(xyzz& a, const aff& q) {
     fe y3 = mul2<FqP>(r, t, ny, ppp);             // r t - Y ppp in one reduction (60 + 8 <= 169): bound 2
     a.zz = mul<FqP>(a.zz, pp); a.zzz = mul<FqP>(a.zzz, ppp);
     a.x = x3; a.y = y3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_expect(was_inf || same_x, 0)) {
+#else
+    if (was_inf || same_x) {
+#endif
+        if (was_inf) { a = xyzz_from_affine(q); norm(a.y); }                       // q.y may be the unnormalized 2p - y
+        else if (is_zero_mod<FqP>(r)) { aff qq = q; norm(qq.y); a = xyzz_dbl_affine(qq); }
+        else a = xyzz_inf();
+    }
 }
 
 // a + b, both XYZZ (12M + 2S on the common path)

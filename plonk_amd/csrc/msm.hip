@@ -1047,12 +1047,14 @@ static uint64_t short_max_setting() {
     if (e && *e) return strtoull(e, nullptr, 0);
     return (1ull << 16) + 4096;
 }
-// MSMs of at most this many scalars (and more than the above) take the 16-bit plan, longer ones the 17-bit plan.
-// PLK_MSM_MID_MAX overrides it (0: no MSM on 16-bit windows).
+// MSMs of at most this many scalars (and more than the above) take the 16-bit plan, longer ones the 17-bit plan.  Measured on one
+// rank of eight at 2^22 gates (MSMs of 2^19 scalars): 19.7-19.9 ms with 17-bit windows against 20.3 ms with 16-bit ones; one rank
+// of four at 2^20 gates (2^18 scalars): 9.89-10.06 against 9.82-10.0 ms; of eight (2^17 scalars): 6.21-6.24 against 6.16-6.21 ms;
+// a proof of 2^20 gates on one GPU (2^20 scalars): 29.2 against 29.7 ms.  PLK_MSM_MID_MAX overrides it (0: no MSM on 16-bit windows).
 static uint64_t mid_max_setting() {
     const char* e = getenv("PLK_MSM_MID_MAX");
     if (e && *e) return strtoull(e, nullptr, 0);
-    return (1ull << 19) + 8192;
+    return (1ull << 18) + 8192;
 }
 // Tables of a narrower plan over a prefix of this rank's points (every MSM of the prover starts at power 0, so a short MSM lies in
 // the prefix) and the gamma powers: windows x (prefix + 3) points.
