@@ -1066,7 +1066,11 @@ struct WorkPool {
         cv_done.wait(lock, [&] { return running == 0; });
         total = 0; job = nullptr;
     }
-    WorkPool() { for (int i = 0; i < HELPERS; ++i) helpers.emplace_back([this] { helper(); }); }
+    WorkPool() {
+        const char* e = getenv("PLK_HOST_HELPERS");          // experiment switch
+        const int n = e && *e ? std::max(0, std::min(31, atoi(e))) : HELPERS;
+        for (int i = 0; i < n; ++i) helpers.emplace_back([this] { helper(); });
+    }
     ~WorkPool() {
         { std::lock_guard<std::mutex> lock(m); stop = true; }
         cv_work.notify_all();
