@@ -271,4 +271,62 @@ __device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& a, int delta) {
     return r;
 }
 
+// ---- point addition shared by four lanes ------------------------------------------------------------------------------------
+// A lone wave issues one VALU instruction per four cycles, so a point addition (fourteen field products one after the other) costs
+// it 6-7 microseconds, and the reductions that end a round are chains of about twenty of them on a chip that is otherwise idle.
+// The products of an addition are not a chain, though: four of them open it, and the ones that follow come in twos and threes.
+// xyzz_add_quad spreads them over the four lanes of a quad (lanes 4k .. 4k+3): every lane holds the same operands, computes one
+// product per step (four steps instead of fourteen) and hands it to the other three through DPP quad permutes.  More instructions
+// in total (about 1.5 times), a third of the latency: for kernels that leave most SIMDs empty.  Control flow around it must be
+// uniform within a quad.
+template <int CTRL>
+__device__ __forceinline__ fe fe_quad_perm(const fe& x) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)x.v[i], (int)x.v[i], CTRL, 0xf, 0xf, false);
+    return r;
+}
+template <int K>
+__device__ __forceinline__ fe fe_quad_bcast(const fe& x) { return fe_quad_perm<K * 0x55>(x); }   // quad_perm(K, K, K, K)
+// lane q of the quad takes x_q
+__device__ __forceinline__ fe fe_sel4(uint32_t q, const fe& x0, const fe& x1, const fe& x2, const fe& x3) {
+    const bool b0 = (q & 1) != 0, b1 = (q & 2) != 0;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t lo = b0 ? x1.v[i] : x0.v[i], hi = b0 ? x3.v[i] : x2.v[i];
+        r.v[i] = b1 ? hi : lo;
+    }
+    return r;
+}
+// a + b for all four lanes of a quad, which hold the same a and b; q = lane & 3.  Same formulas as xyzz_add; Y3 comes out as the sum
+// of two reduced products (bound 4, the bound a stored Y may have) instead of one merged reduction.
+__device__ __forceinline__ xyzz xyzz_add_quad(const xyzz& a, const xyzz& b, uint32_t q) {
+    if (xyzz_is_inf(a)) return b;
+    if (xyzz_is_inf(b)) return a;
+    const fe m1 = mul<FqP>(fe_sel4(q, a.x, b.x, a.y, b.y), fe_sel4(q, b.zz, a.zz, b.zzz, a.zzz));
+    const fe u1 = fe_quad_bcast<0>(m1), u2 = fe_quad_bcast<1>(m1), s1 = fe_quad_bcast<2>(m1), s2 = fe_quad_bcast<3>(m1);
+    fe p = sub2<FqP>(u2, u1); norm(p);            // bound 4
+    fe r = sub2<FqP>(s2, s1); norm(r);            // bound 4
+    if (is_zero_mod<FqP>(p)) {
+        if (is_zero_mod<FqP>(r)) return xyzz_dbl(a);
+        return xyzz_inf();
+    }
+    const fe m2 = mul<FqP>(fe_sel4(q, a.zz, a.zzz, p, r), fe_sel4(q, b.zz, b.zzz, p, r));
+    const fe zzab = fe_quad_bcast<0>(m2), zzzab = fe_quad_bcast<1>(m2), pp = fe_quad_bcast<2>(m2), rr = fe_quad_bcast<3>(m2);
+    const fe m3 = mul<FqP>(fe_sel4(q, p, u1, zzab, zzab), pp);
+    const fe ppp = fe_quad_bcast<0>(m3), qv = fe_quad_bcast<1>(m3);
+    xyzz o;
+    o.zz = fe_quad_bcast<2>(m3);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.x.v[i] = rr.v[i] + FqP::SUB6X3[i] - ppp.v[i] - 2 * qv.v[i];
+    norm(o.x);                                    // bound 8
+    const fe t = sub8<FqP>(qv, o.x);              // bound 10, limbs < 3 * 2^29
+    const fe ns1 = sub2<FqP>(fe_zero(), s1);      // 2p - S1: bound 2, limbs < 2^30
+    const fe m4 = mul<FqP>(fe_sel4(q, r, ns1, zzzab, zzzab), fe_sel4(q, t, ppp, ppp, ppp));
+    o.y = add(fe_quad_bcast<0>(m4), fe_quad_bcast<1>(m4)); norm(o.y);   // r t - S1 ppp: bound 4
+    o.zzz = fe_quad_bcast<2>(m4);
+    return o;
+}
+
 }  // namespace plk

@@ -375,8 +375,14 @@ struct ReduceBatch {
 };
 // bucket_sums[b] = flushed[b] (if the bucket ended inside a run) + the tails of all lanes whose run ended inside bucket b.
 // FOLD_LANES lanes per bucket share the tails, a shuffle tree joins them.
-template <int FOLD_LANES, int C>
+template <int FOLD_LANES, int C, int G = 1>
 __device__ __forceinline__ void fold_body(const ReduceBatch& rb);
+// a + b by one lane (G = 1) or by the four lanes of a quad together (G = 4, xyzz_add_quad)
+template <int G>
+__device__ __forceinline__ xyzz add_g(const xyzz& a, const xyzz& b, uint32_t q) {
+    if constexpr (G == 4) return xyzz_add_quad(a, b, q);
+    else return xyzz_add(a, b);
+}
 // Two builds of every reduction kernel.  "side": held to 128 registers so that its waves fit beside two accumulation waves per SIMD
 // (they spill, which costs nothing that matters: these reductions run beside the accumulation kernels of later MSMs).
 // "tail": no register limit, for the reduction that ends a batch: nothing else is running then, and the round waits for it.
@@ -387,7 +393,11 @@ __global__ void __launch_bounds__(256) SIDE_KERNEL_VGPRS k_msm_fold(ReduceBatch 
 }
 template <int FOLD_LANES, int C>
 __global__ void __launch_bounds__(256) k_msm_fold_tail(ReduceBatch rb) { fold_body<FOLD_LANES, C>(rb); }
+// "quad": a tail build in which four lanes share every addition (a third of the latency, one and a half times the instructions), for
+// the launches that leave most of the chip empty
 template <int FOLD_LANES, int C>
+__global__ void __launch_bounds__(256) k_msm_fold_quad(ReduceBatch rb) { fold_body<FOLD_LANES, C, 4>(rb); }
+template <int FOLD_LANES, int C, int G>
 __device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
     constexpr int BUCKETS = MsmPlan<C>::BUCKETS;
     const uint32_t* __restrict__ bucket_start = rb.bucket_start[blockIdx.y];
@@ -395,7 +405,7 @@ __device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
     const uint32_t* __restrict__ flushed = rb.flushed[blockIdx.y];
     const uint32_t tail_stride = rb.tail_stride[blockIdx.y], lanes_launched = rb.lanes_launched[blockIdx.y];
     uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t = (blockIdx.x * 256 + threadIdx.x) / G, q = threadIdx.x & 3;   // G lanes share the work of one
     const uint32_t b = t / FOLD_LANES, j = t % FOLD_LANES;
     const uint32_t first = bucket_start[b], last = bucket_start[b + 1], n_entries = bucket_start[BUCKETS];
     const uint32_t run = acc_run_length(n_entries, lanes_launched);
@@ -403,19 +413,19 @@ __device__ __forceinline__ void fold_body(const ReduceBatch& rb) {
     if (last > first) {
         // lane l ends its run at entry (l + 1) * run - 1 (the final lane at n_entries - 1): it belongs here when that entry is in [first, last)
         const uint32_t m_lo = first / run + 1, m_hi = last / run;
-        for (uint32_t m = m_lo + j; m <= m_hi; m += FOLD_LANES) acc = xyzz_add(acc, ld_tail(tails, tail_stride, m - 1));
+        for (uint32_t m = m_lo + j; m <= m_hi; m += FOLD_LANES) acc = add_g<G>(acc, ld_tail(tails, tail_stride, m - 1), q);
         if (j == FOLD_LANES - 1 && last % run != 0) {
-            if (last < n_entries) acc = xyzz_add(acc, ld_xyzz(flushed + (size_t)b * XYZZ_WORDS));
-            else acc = xyzz_add(acc, ld_tail(tails, tail_stride, m_hi));   // the final, shorter run
+            if (last < n_entries) acc = add_g<G>(acc, ld_xyzz(flushed + (size_t)b * XYZZ_WORDS), q);
+            else acc = add_g<G>(acc, ld_tail(tails, tail_stride, m_hi), q);   // the final, shorter run
         }
     }
     // only the lanes whose partner belongs to the same bucket add: a lane past the end of the wave would receive its own value back,
     // take the doubling branch, and the whole wave would execute that branch beside the addition at every level
     for (int s = FOLD_LANES / 2; s > 0; s >>= 1) {
-        const xyzz other = shfl_down_xyzz(acc, s);
-        if (j < (uint32_t)s) acc = xyzz_add(acc, other);
+        const xyzz other = shfl_down_xyzz(acc, s * G);
+        if (j < (uint32_t)s) acc = add_g<G>(acc, other, q);
     }
-    if (j == 0) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
+    if (j == 0 && (G == 1 || q == 0)) st_xyzz(bucket_sums + (size_t)b * XYZZ_WORDS, acc);
 }
 
 // Marginal sums: output o = the sum of all buckets whose index has field d (bits [4d, 4d+4); the top field may be narrower) equal
@@ -432,8 +442,9 @@ struct MargPlan {
     static_assert(PARTIALS % 64 == 0, "whole waves");
 };
 constexpr int MARG_PARTIALS_MAX = MargPlan<MSM_C_LONG>::PARTIALS;
-template <int C> __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb);
+template <int C, int G = 1> __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb);
 template <int C> __device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb);
+template <int C> __device__ __forceinline__ void marginals_join_quad_body(const ReduceBatch& rb);
 template <int C>
 __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_part(ReduceBatch rb) {
     PLK_SIDE_PRIO();   // short kernel on the critical path of the pipeline: issue ahead of co-resident accumulation waves
@@ -449,11 +460,15 @@ __global__ void __launch_bounds__(64) SIDE_KERNEL_VGPRS k_msm_marginals_join(Red
 template <int C>
 __global__ void __launch_bounds__(64) k_msm_marginals_join_tail(ReduceBatch rb) { marginals_join_body<C>(rb); }
 template <int C>
+__global__ void __launch_bounds__(64) k_msm_marginals_part_quad(ReduceBatch rb) { marginals_part_body<C, 4>(rb); }
+template <int C>
+__global__ void __launch_bounds__(256) k_msm_marginals_join_quad(ReduceBatch rb) { marginals_join_quad_body<C>(rb); }
+template <int C, int G>
 __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb) {
     using M = MargPlan<C>;
     const uint32_t* __restrict__ bucket_sums = rb.bucket_sums[blockIdx.y];
     uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
-    const uint32_t lane_id = blockIdx.x * 64 + threadIdx.x;     // < PARTIALS
+    const uint32_t lane_id = (blockIdx.x * 64 + threadIdx.x) / G, q = threadIdx.x & 3;     // < PARTIALS
     uint32_t o, p, stride;
     if (lane_id < M::NA * M::PART_A) { o = lane_id / M::PART_A; p = lane_id % M::PART_A; stride = M::PART_A; }
     else { const uint32_t r = lane_id - M::NA * M::PART_A; o = M::NA + r / M::PART_B; p = r % M::PART_B; stride = M::PART_B; }
@@ -464,9 +479,9 @@ __device__ __forceinline__ void marginals_part_body(const ReduceBatch& rb) {
     for (int j = 0; j < MARG_K; ++j) {
         const uint32_t m = p + (uint32_t)j * stride;            // neighbouring lanes read neighbouring members
         const uint32_t idx = ((m >> shift) << (shift + bits)) | (v << shift) | (m & ((1u << shift) - 1));
-        acc = xyzz_add(acc, ld_xyzz(bucket_sums + (size_t)idx * XYZZ_WORDS));
+        acc = add_g<G>(acc, ld_xyzz(bucket_sums + (size_t)idx * XYZZ_WORDS), q);
     }
-    st_xyzz(part + (size_t)lane_id * XYZZ_WORDS, acc);
+    if (G == 1 || q == 0) st_xyzz(part + (size_t)lane_id * XYZZ_WORDS, acc);
 }
 template <int C>
 __device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb) {
@@ -483,6 +498,41 @@ __device__ __forceinline__ void marginals_join_body(const ReduceBatch& rb) {
         if (lane < (uint32_t)s) acc = xyzz_add(acc, other);
     }
     if (lane == 0) {
+        uint32_t* dst = out + (size_t)o * 32;
+        const fe to_r = fe_const(FqP::TO_R);
+        st_fe<FqP>(dst, mul<FqP>(acc.x, to_r));
+        st_fe<FqP>(dst + 8, mul<FqP>(acc.y, to_r));
+        st_fe<FqP>(dst + 16, mul<FqP>(acc.zz, to_r));
+        st_fe<FqP>(dst + 24, mul<FqP>(acc.zzz, to_r));
+    }
+}
+
+// The join with four lanes per addition: a workgroup of four waves per output, 64 quads that take the partial sums in turn, a
+// shuffle tree over the sixteen quads of a wave, the four waves' sums through LDS and two more levels in the first wave.
+template <int C>
+__device__ __forceinline__ void marginals_join_quad_body(const ReduceBatch& rb) {
+    using M = MargPlan<C>;
+    __shared__ uint32_t wave_sums[4 * XYZZ_WORDS];
+    const uint32_t* __restrict__ part = rb.marg_part[blockIdx.y];
+    uint32_t* __restrict__ out = rb.marg_dev[blockIdx.y];
+    const uint32_t o = blockIdx.x, lane = threadIdx.x >> 2, q = threadIdx.x & 3, wave = threadIdx.x >> 6, lane_in_wave = lane & 15;
+    const uint32_t first = o < M::NA ? o * M::PART_A : M::NA * M::PART_A + (o - M::NA) * M::PART_B, count = o < M::NA ? M::PART_A : M::PART_B;
+    xyzz acc = xyzz_inf();
+#pragma unroll 1
+    for (uint32_t k = lane; k < count; k += 64) acc = xyzz_add_quad(acc, ld_xyzz(part + (size_t)(first + k) * XYZZ_WORDS), q);
+    for (int s = 8; s > 0; s >>= 1) {   // lanes without a partner must not add their own value
+        const xyzz other = shfl_down_xyzz(acc, 4 * s);
+        if (lane_in_wave < (uint32_t)s) acc = xyzz_add_quad(acc, other, q);
+    }
+    if (lane_in_wave == 0 && q == 0) st_xyzz(wave_sums + wave * XYZZ_WORDS, acc);
+    __syncthreads();
+    if (wave != 0) return;
+    acc = lane < 4 ? ld_xyzz(wave_sums + lane * XYZZ_WORDS) : xyzz_inf();
+    for (int s = 2; s > 0; s >>= 1) {
+        const xyzz other = shfl_down_xyzz(acc, 4 * s);
+        if (lane < (uint32_t)s) acc = xyzz_add_quad(acc, other, q);
+    }
+    if (threadIdx.x == 0) {
         uint32_t* dst = out + (size_t)o * 32;
         const fe to_r = fe_const(FqP::TO_R);
         st_fe<FqP>(dst, mul<FqP>(acc.x, to_r));
@@ -844,12 +894,24 @@ static void launch_reduction(hipStream_t st, const ReduceBatch& rb, uint64_t tai
     constexpr int BUCKETS = MsmPlan<C>::BUCKETS, PARTIALS = MargPlan<C>::PARTIALS, OUTPUTS = MsmPlan<C>::MARGINALS;
     // runs that end inside an average bucket; two lanes per bucket keep the fold cheap, more lanes keep its serial chain short
     if (tail) {
-        // the batch ends with this reduction: all registers, no spills
-        if (tails_per_bucket <= 12) hipLaunchKernelGGL((k_msm_fold_tail<2, C>), dim3(BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
-        else if (tails_per_bucket <= 48) hipLaunchKernelGGL((k_msm_fold_tail<4, C>), dim3(BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
-        else hipLaunchKernelGGL((k_msm_fold_tail<8, C>), dim3(BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
-        hipLaunchKernelGGL(k_msm_marginals_part_tail<C>, dim3(PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
-        hipLaunchKernelGGL(k_msm_marginals_join_tail<C>, dim3(OUTPUTS, rb.n), dim3(64), 0, st, rb);
+        // the batch ends with this reduction: all registers, no spills; and where a launch would leave most SIMDs without a wave
+        // (1024 of them), four lanes share every addition
+        static const bool quads = !(getenv("PLK_NO_QUADS") && atoi(getenv("PLK_NO_QUADS")));
+        const int fl = tails_per_bucket <= 12 ? 2 : tails_per_bucket <= 48 ? 4 : 8;
+        const uint64_t fold_waves = (uint64_t)BUCKETS * fl / 64 * rb.n;
+        if (quads && fold_waves * 4 <= 2048) {
+            if (fl == 2) hipLaunchKernelGGL((k_msm_fold_quad<2, C>), dim3(BUCKETS * 2 * 4 / 256, rb.n), dim3(256), 0, st, rb);
+            else if (fl == 4) hipLaunchKernelGGL((k_msm_fold_quad<4, C>), dim3(BUCKETS * 4 * 4 / 256, rb.n), dim3(256), 0, st, rb);
+            else hipLaunchKernelGGL((k_msm_fold_quad<8, C>), dim3(BUCKETS * 8 * 4 / 256, rb.n), dim3(256), 0, st, rb);
+        } else {
+            if (fl == 2) hipLaunchKernelGGL((k_msm_fold_tail<2, C>), dim3(BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
+            else if (fl == 4) hipLaunchKernelGGL((k_msm_fold_tail<4, C>), dim3(BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
+            else hipLaunchKernelGGL((k_msm_fold_tail<8, C>), dim3(BUCKETS * 8 / 256, rb.n), dim3(256), 0, st, rb);
+        }
+        if (quads && (uint64_t)PARTIALS / 64 * rb.n * 4 <= 1536) hipLaunchKernelGGL(k_msm_marginals_part_quad<C>, dim3(PARTIALS * 4 / 64, rb.n), dim3(64), 0, st, rb);
+        else hipLaunchKernelGGL(k_msm_marginals_part_tail<C>, dim3(PARTIALS / 64, rb.n), dim3(64), 0, st, rb);
+        if (quads && (uint64_t)OUTPUTS * rb.n * 4 <= 2048) hipLaunchKernelGGL(k_msm_marginals_join_quad<C>, dim3(OUTPUTS, rb.n), dim3(256), 0, st, rb);
+        else hipLaunchKernelGGL(k_msm_marginals_join_tail<C>, dim3(OUTPUTS, rb.n), dim3(64), 0, st, rb);
     } else {
         if (tails_per_bucket <= 12) hipLaunchKernelGGL((k_msm_fold<2, C>), dim3(BUCKETS * 2 / 256, rb.n), dim3(256), 0, st, rb);
         else if (tails_per_bucket <= 48) hipLaunchKernelGGL((k_msm_fold<4, C>), dim3(BUCKETS * 4 / 256, rb.n), dim3(256), 0, st, rb);
