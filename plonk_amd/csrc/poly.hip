@@ -94,15 +94,23 @@ __device__ __forceinline__ fe div_local_sum(const uint32_t* __restrict__ c, uint
     return h;
 }
 // V_t <- sum_{u >= t} V_u w^(u - t) over the 256 threads of the workgroup (Kogge-Stone, eight steps); w in the 2^261 form.
-// Every thread passes a normalized value; the result is normalized with bound 2.
-__device__ __forceinline__ fe div_block_suffix_scan(fe v, fe w, uint32_t* lds /* 2 x 256 x 9 words */) {
+// Every thread passes a normalized value; the result is normalized with bound 2.  The weight of step d is w^(2^d): squared on the
+// way (weight_of(d) == nullptr) or read from a table the host prepared (the powers z^(2^k) of the evaluation point: every thread of
+// every workgroup would otherwise square the same eight values, half of the products of a scan).
+struct DivPowers {
+    W8 p[14];              // z^(2^k), k = 0 .. 13, in the 2^261 form (canonical words)
+};
+template <bool TABLE>
+__device__ __forceinline__ fe div_block_suffix_scan(fe v, fe w, const DivPowers* table, int first_power, uint32_t* lds /* 2 x 256 x 9 words */) {
     const uint32_t t = threadIdx.x;
     uint32_t* cur = lds;
     uint32_t* nxt = lds + DIV_THREADS * 9;
 #pragma unroll
     for (int i = 0; i < 9; ++i) cur[t * 9 + i] = v.v[i];
     __syncthreads();
-    for (int d = 1; d < DIV_THREADS; d <<= 1) {
+    int step = 0;
+    for (int d = 1; d < DIV_THREADS; d <<= 1, ++step) {
+        if (TABLE) w = fe_of(table->p[first_power + step]);
         if (t + d < DIV_THREADS) {
             fe o;
 #pragma unroll
@@ -114,7 +122,7 @@ __device__ __forceinline__ fe div_block_suffix_scan(fe v, fe w, uint32_t* lds /*
         for (int i = 0; i < 9; ++i) nxt[t * 9 + i] = v.v[i];
         __syncthreads();
         uint32_t* sw = cur; cur = nxt; nxt = sw;
-        w = mul<FrP>(w, w);
+        if (!TABLE) w = mul<FrP>(w, w);
     }
     return mul<FrP>(v, fe_const(FrP::ONE));   // bound <= 3 + 2 * 8 back to 2
 }
@@ -137,6 +145,7 @@ struct DivBatch {
     uint32_t apply_blocks[DIV_BATCH_MAX];
     uint32_t log_block[DIV_BATCH_MAX];     // log2 of the coefficients per block
     W8 zeta, scale;
+    DivPowers zp;
     uint32_t cyc_world, cyc_rank, cyc_log_block;
 };
 template <int LOG_L>
@@ -147,10 +156,10 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_sums(DivBatch db, uint32_t 
     if (blockIdx.x >= db.nb[mb]) return;
     const uint32_t* __restrict__ c = db.c[mb];
     const uint64_t len = db.len[mb];
-    const fe z = to_rp(fe_of(db.zeta));
+    const fe z = fe_of(db.zp.p[0]);
     fe s = div_local_sum<LOG_L>(c, ((uint64_t)blockIdx.x * DIV_THREADS + threadIdx.x) << LOG_L, len, z);
     norm(s);
-    const fe tot = div_block_suffix_scan(s, div_pow2(z, LOG_L), lds);   // thread 0 ends up with the whole block
+    const fe tot = div_block_suffix_scan<true>(s, z, &db.zp, LOG_L, lds);   // thread 0 ends up with the whole block
     if (threadIdx.x == 0) st_lazy(db.A[mb] + 8ull * blockIdx.x, tot);
 }
 // carry[b] = h at the first coefficient of block b + 1 (zero for the last block); h0 = h_0, canonical.  One workgroup per polynomial.
@@ -165,7 +174,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_carries(DivBatch db) {
     const uint32_t nb = db.nb[mb];
     const uint32_t t = threadIdx.x;
     const uint32_t m = (nb + DIV_THREADS - 1) / DIV_THREADS;            // blocks per thread
-    const fe ze = div_pow2(to_rp(fe_of(db.zeta)), (int)db.log_block[mb]);   // z^E
+    const fe ze = fe_of(db.zp.p[db.log_block[mb]]);                      // z^E, E = 2^11 or 2^13
     // weight between the chunks of neighbouring threads: ze^m
     fe wm = fe_const(FrP::ONE);
     for (uint32_t k = 0; k < m; ++k) wm = mul<FrP>(wm, ze);
@@ -177,7 +186,7 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_carries(DivBatch db) {
         s = add(a, mul<FrP>(s, ze));
     }
     norm(s);
-    const fe head = div_block_suffix_scan(s, wm, lds);                  // C at the first block of this thread's chunk
+    const fe head = div_block_suffix_scan<false>(s, wm, nullptr, 0, lds);   // C at the first block of this thread's chunk
 #pragma unroll
     for (int i = 0; i < 9; ++i) tops[t * 9 + i] = head.v[i];
     __syncthreads();
@@ -229,14 +238,14 @@ __global__ void __launch_bounds__(DIV_THREADS) k_div_apply(DivBatch db, uint32_t
         for (uint64_t b = b_lo; !need && b <= b_hi; ++b) need = b % cyc_world == cyc_rank;
         if (!need) return;
     }
-    const fe z = to_rp(fe_of(db.zeta));
-    const fe zl = div_pow2(z, LOG_L);
+    const fe z = fe_of(db.zp.p[0]);
+    const fe zl = fe_of(db.zp.p[LOG_L]);
     const uint64_t lo = (uint64_t)blk * BLOCK + ((uint64_t)t << LOG_L);
     const fe cin = ld_fe(carry + 8ull * blk);
     fe s = div_local_sum<LOG_L>(c, lo, len, z);
     if (t == DIV_THREADS - 1) s = add(s, mul<FrP>(cin, zl));            // h at this thread's first coefficient, given the block's carry
     norm(s);
-    const fe head = div_block_suffix_scan(s, zl, lds);                  // h at every thread's first coefficient
+    const fe head = div_block_suffix_scan<true>(s, zl, &db.zp, LOG_L, lds);   // h at every thread's first coefficient
 #pragma unroll
     for (int i = 0; i < 9; ++i) heads[t * 9 + i] = head.v[i];
     __syncthreads();
@@ -275,6 +284,13 @@ int32_t division_enqueue_batch(plk_ctx* ctx, hipStream_t st, uint32_t count, con
     memset(&db, 0, sizeof(db));
     db.zeta = w8_of(zeta);
     db.scale = w8_of(scale ? scale : host::FR.one);
+    {
+        // z^(2^k) in the 2^261 form: the host's elements carry 2^256, a product with 32 supplies the rest
+        using namespace host;
+        const el f32 = from_u64(FR, 32);
+        el zk = el_load(zeta);
+        for (int k = 0; k < 14; ++k) { db.zp.p[k] = w8_of(mul(FR, zk, f32)); zk = mul(FR, zk, zk); }
+    }
     db.cyc_world = ctx->cyc_world; db.cyc_rank = ctx->cyc_rank; db.cyc_log_block = ctx->cyc_log_block;
     uint32_t n_short = 0, n = 0, max_nb[2] = {0, 0}, max_apply[2] = {0, 0};
     // A batch of several long polynomials fills the chip whatever the block size, and then the work per coefficient decides (the
