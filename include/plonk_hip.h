@@ -59,8 +59,9 @@ int32_t plk_sync(plk_ctx* ctx);
 int32_t plk_copy_dev(plk_ctx* ctx, void* dev_dst, const void* dev_src, uint64_t bytes, uint64_t total_bytes);
 
 /* ---- structured reference string (KZGProverKey, src/prover.rs:32; built by PCS::trim, src/main.rs:183)
- * HBM together with its window tables (2^(17 j) * P for each window j; 16- and 13-bit tables over a prefix).  With n_shards > 1 this context
- * HBM together with its window tables (2^(16 j) * P for each window j).  With n_shards > 1 this context
+ * powers_of_g[0..len) and powers_of_gamma_g[0..3) as affine x||y.  The library keeps them resident in
+ * HBM together with its window tables (2^(17 j) * P for each window j; 16- and 13-bit tables over a
+ * prefix of the points).  With n_shards > 1 this context
  * keeps only powers [shard_first, shard_first + shard_len) and every MSM it runs is the partial sum over
  * that range; the gamma powers belong to the shard that contains index 0. */
 int32_t plk_srs_load(plk_ctx* ctx, const uint64_t* g_xy_host, uint64_t len, const uint64_t* gamma_g_xy_host);
